@@ -1,0 +1,61 @@
+/*
+ * philox.h — Philox4x32-10 counter-based RNG (Salmon et al., SC'11), the
+ * replacement for the per-pixel XORWOW curandState of reference main.cu:108-117.
+ *
+ * Stream definition (identical in the oracle and in the kernels):
+ *   key     = (seed_lo, seed_hi)
+ *   counter = (block, lane_stream, pixel, sample)
+ * A path (pixel, sample) draws its uniforms sequentially; draw k is word k&3 of
+ * block k>>2 with lane_stream = 0.  Constant-medium free-flight draws use
+ * lane_stream = 1 + medium_slot and block = bounce, word 0, so that they do not
+ * depend on the order in which media are visited.
+ * This is bit-compatible with rocRAND's device engine initialised as
+ * rocrand_init(seed, subsequence = pixel | sample<<32, offset = 4*block [+ stream<<34]).
+ * Uniforms are in (0,1] like curand_uniform (needed by log(xi), Volumes.cuh:40).
+ */
+#ifndef RT_PHILOX_H
+#define RT_PHILOX_H
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define RT_HD __host__ __device__ __forceinline__
+#else
+#define RT_HD inline
+#endif
+
+struct rt_u32x4 { uint32_t x, y, z, w; };
+
+RT_HD uint32_t rt_mulhi32(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
+#endif
+}
+
+RT_HD rt_u32x4 rt_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                uint32_t k0, uint32_t k1)
+{
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    const uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = rt_mulhi32(M0, c0), lo0 = M0 * c0;
+        uint32_t hi1 = rt_mulhi32(M1, c2), lo1 = M1 * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0;
+        uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += W0; k1 += W1;
+    }
+    rt_u32x4 o = {c0, c1, c2, c3};
+    return o;
+}
+
+/* (0,1]: 2^-32 + v*2^-32, v rounded to float first (same as rocrand_uniform) */
+RT_HD float rt_u32_to_uniform(uint32_t v)
+{
+    return 2.3283064e-10f + ((float)v * 2.3283064e-10f);
+}
+
+#endif

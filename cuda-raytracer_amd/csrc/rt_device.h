@@ -1,0 +1,597 @@
+/*
+ * rt_device.h — device-side scene tables and the per-lane intersection / shading code.
+ *
+ * One lane = one path.  Nothing here is virtual: the reference's Hitable / Material /
+ * Texture hierarchies (Hitable.cuh:23-28, Material.cuh:44-49, Texture.cuh:7-11) are
+ * type-tagged table rows, and every hit()/scatter()/value() body is a switch arm that
+ * keeps the reference's operand order so results are reproducible against the oracle
+ * (the library is compiled with -ffp-contract=off; division and sqrt are IEEE).
+ *
+ * Closest hit works in two steps to keep the live state small: the search only carries
+ * (t, object, group, face) and the full record (p, normal, u, v, material) is rebuilt
+ * once for the winner by re-running that one primitive — the arithmetic is the same, so
+ * the record is bit-identical to what the reference builds on the fly.
+ */
+#ifndef RT_DEVICE_H
+#define RT_DEVICE_H
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+#include "../../include/rt_scene.h"
+#include "philox.h"
+#include "rt_host.h"
+
+#define RT_PI_D 3.14159265358979323846
+#define RT_STACK_DEPTH 48        /* per-lane BVH stack entries (LDS) */
+#define RT_BLOCK 256
+
+struct DScene {
+    const DObj*        __restrict__ objs;
+    const rt_xform_op* __restrict__ ops;
+    const rt_material* __restrict__ mats;
+    const rt_texture*  __restrict__ texs;
+    const uint8_t*     __restrict__ image;
+    const rt_bvh_node* __restrict__ nodes;
+    const int32_t*     __restrict__ items;
+    int32_t world;
+    int32_t n_media;
+    rt_camera cam;
+};
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 mk(float a, float b, float c) { V3 r = {a, b, c}; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator*(float t, V3 v) { return mk(t * v.x, t * v.y, t * v.z); }
+__device__ __forceinline__ V3 operator/(V3 v, float t) { return mk(v.x / t, v.y / t, v.z / t); }
+__device__ __forceinline__ V3 operator-(V3 v) { return mk(-v.x, -v.y, -v.z); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b)
+{
+    return mk((a.y * b.z - a.z * b.y), (-(a.x * b.z - a.z * b.x)), (a.x * b.y - a.y * b.x));
+}
+__device__ __forceinline__ float length(V3 v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }
+__device__ __forceinline__ V3 unit(V3 v) { return v / length(v); }
+__device__ __forceinline__ V3 ld3(const float* f) { return mk(f[0], f[1], f[2]); }
+
+struct DRay { V3 o, d; float time; };
+__device__ __forceinline__ V3 at(const DRay& r, float t) { return r.o + t * r.d; }
+
+/* what the closest-hit search carries */
+struct HitLite {
+    float   t;
+    int32_t obj;   /* winning leaf object, -1 = miss */
+    int32_t grp;   /* group object it was reached through, -1 = directly in the world list */
+};
+
+/* the rebuilt record (Intersect, Hitable.cuh:10-22) */
+struct HitRec {
+    float t, u, v;
+    V3 p, n;
+    int32_t material, prim_id, front;
+};
+
+/* ------------------------------------------------------------------ RNG ---- */
+struct PathRng {
+    uint32_t k0, k1, pixel, sample, idx;
+    uint32_t b0, b1, b2, b3;
+};
+__device__ __forceinline__ void rng_start(PathRng& g, uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample)
+{
+    g.k0 = k0; g.k1 = k1; g.pixel = pixel; g.sample = sample; g.idx = 0;
+    g.b0 = g.b1 = g.b2 = g.b3 = 0;
+}
+__device__ __forceinline__ float rng_next(PathRng& g)
+{
+    uint32_t w = g.idx & 3u;
+    if (w == 0) {
+        rt_u32x4 r = rt_philox4x32_10(g.idx >> 2, 0u, g.pixel, g.sample, g.k0, g.k1);
+        g.b0 = r.x; g.b1 = r.y; g.b2 = r.z; g.b3 = r.w;
+    }
+    g.idx++;
+    uint32_t v = w == 0 ? g.b0 : (w == 1 ? g.b1 : (w == 2 ? g.b2 : g.b3));
+    return rt_u32_to_uniform(v);
+}
+__device__ __forceinline__ float rng_medium(const PathRng& g, uint32_t bounce, int slot)
+{
+    rt_u32x4 r = rt_philox4x32_10(bounce, 1u + (uint32_t)slot, g.pixel, g.sample, g.k0, g.k1);
+    return rt_u32_to_uniform(r.x);
+}
+
+/* ----------------------------------------------------------- primitives ---- */
+/* Each *_t function answers "does it hit in (tMin,tMax), and at what t" with the
+ * reference's arithmetic; the *_rec twin rebuilds the record for that t. */
+
+/* Sphere::hit Sphere.cuh:25-56 / MovingSphere::hit :91-120 (centre passed in) */
+__device__ __forceinline__ bool sphere_t(V3 centre, float radius, const DRay& r, float tMin, float tMax, float& t)
+{
+    V3 oc = r.o - centre;
+    float a = dot(r.d, r.d);
+    float b = 2.f * dot(oc, r.d);
+    float c = dot(oc, oc) - radius * radius;
+    float discrim = b * b - 4.f * a * c;
+    if (discrim > 0) {
+        float sq = sqrtf(discrim);
+        float temp = (-b - sq) / (2 * a);
+        if (temp < tMax && temp > tMin) { t = temp; return true; }
+        temp = (-b + sq) / (2 * a);
+        if (temp < tMax && temp > tMin) { t = temp; return true; }
+    }
+    return false;
+}
+__device__ __forceinline__ V3 moving_centre(const float* f, float time)
+{
+    V3 c0 = ld3(f), c1 = ld3(f + 3);
+    return c0 + ((time - f[6]) / (f[7] - f[6])) * (c1 - c0);     /* Sphere.cuh:86-89 */
+}
+
+/* XYRect/XZRect/YZRect::hit Rectangle.cuh:24-38,55-69,86-100; KA = fixed axis */
+template <int KA>
+__device__ __forceinline__ bool rect_t(float a0, float a1, float b0, float b1, float k, const DRay& r,
+                                       float t0, float t1, float& t_out)
+{
+    float ok = KA == 2 ? r.o.z : (KA == 1 ? r.o.y : r.o.x);
+    float dk = KA == 2 ? r.d.z : (KA == 1 ? r.d.y : r.d.x);
+    float oa = KA == 0 ? r.o.y : r.o.x;
+    float da = KA == 0 ? r.d.y : r.d.x;
+    float ob = KA == 2 ? r.o.y : r.o.z;
+    float db = KA == 2 ? r.d.y : r.d.z;
+    float t = (k - ok) / dk;
+    if (t < t0 || t > t1) return false;
+    float a = oa + t * da;
+    float b = ob + t * db;
+    if (a < a0 || a > a1 || b < b0 || b > b1) return false;
+    t_out = t;
+    return true;
+}
+__device__ __forceinline__ bool rect_any_t(int type, const float* f, const DRay& r, float t0, float t1, float& t)
+{
+    if (type == RT_OBJ_RECT_XY) return rect_t<2>(f[0], f[1], f[2], f[3], f[4], r, t0, t1, t);
+    if (type == RT_OBJ_RECT_XZ) return rect_t<1>(f[0], f[1], f[2], f[3], f[4], r, t0, t1, t);
+    return rect_t<0>(f[0], f[1], f[2], f[3], f[4], r, t0, t1, t);
+}
+/* record of a rect hit at t: u,v,p and the ray-facing axis normal (setFaceNormal, Hitable.cuh:17-21) */
+template <int KA>
+__device__ __forceinline__ void rect_rec(float a0, float a1, float b0, float b1, const DRay& r, float t, HitRec& h)
+{
+    float oa = KA == 0 ? r.o.y : r.o.x;
+    float da = KA == 0 ? r.d.y : r.d.x;
+    float ob = KA == 2 ? r.o.y : r.o.z;
+    float db = KA == 2 ? r.d.y : r.d.z;
+    float dk = KA == 2 ? r.d.z : (KA == 1 ? r.d.y : r.d.x);
+    float a = oa + t * da;
+    float b = ob + t * db;
+    h.u = (a - a0) / (a1 - a0);
+    h.v = (b - b0) / (b1 - b0);
+    h.t = t;
+    h.p = at(r, t);
+    bool front = dk < 0;           /* dot(dir, +axis) < 0 */
+    float s = front ? 1.f : -1.f;
+    h.n = mk(KA == 0 ? s : (front ? 0.f : -0.f), KA == 1 ? s : (front ? 0.f : -0.f), KA == 2 ? s : (front ? 0.f : -0.f));
+    h.front = front;
+}
+
+/* Box = six rects in list order (Box.cuh:24-36); returns the winning face */
+__device__ __forceinline__ bool box_t(const float* f, const DRay& r, float t0, float t1, float& t_out, int& face)
+{
+    bool any = false;
+    float closest = t1, t;
+    if (rect_t<2>(f[0], f[3], f[1], f[4], f[5], r, t0, closest, t)) { any = true; closest = t; face = 0; }
+    if (rect_t<2>(f[0], f[3], f[1], f[4], f[2], r, t0, closest, t)) { any = true; closest = t; face = 1; }
+    if (rect_t<1>(f[0], f[3], f[2], f[5], f[4], r, t0, closest, t)) { any = true; closest = t; face = 2; }
+    if (rect_t<1>(f[0], f[3], f[2], f[5], f[1], r, t0, closest, t)) { any = true; closest = t; face = 3; }
+    if (rect_t<0>(f[1], f[4], f[2], f[5], f[3], r, t0, closest, t)) { any = true; closest = t; face = 4; }
+    if (rect_t<0>(f[1], f[4], f[2], f[5], f[0], r, t0, closest, t)) { any = true; closest = t; face = 5; }
+    t_out = closest;
+    return any;
+}
+
+/* Triangle::hit Triangle.cuh:21-46 with the unit normal and plane offset precomputed on the
+ * host by the same expressions (f[9..12]); plus the tMin<t<tMax filter */
+__device__ __forceinline__ bool triangle_t(const float* f, const DRay& r, float tMin, float tMax, float& t_out)
+{
+    V3 v0 = ld3(f), v1 = ld3(f + 3), v2 = ld3(f + 6), normal = ld3(f + 9);
+    float d = f[12];
+    float distance = (-dot(r.o, normal) + d) / (dot(r.d, normal));
+    if (distance > FLT_EPSILON) {
+        V3 inter = at(r, distance);
+        float a = dot(cross(v1 - v0, inter - v0), normal);
+        float b = dot(cross(v2 - v1, inter - v1), normal);
+        float c = dot(cross(v0 - v2, inter - v2), normal);
+        if (a > 0 && b > 0 && c > 0) {
+            if (!(distance < tMax && distance > tMin)) return false;
+            t_out = distance;
+            return true;
+        }
+    }
+    return false;
+}
+
+/* ------------------------------------------------------------ transforms ---- */
+/* Translate::hit Transform.cuh:19-28 and RotateY::hit :90-112, ray side */
+__device__ __forceinline__ void apply_op(const rt_xform_op& op, DRay& r)
+{
+    if (op.type == RT_OP_TRANSLATE) {
+        r.o = r.o - mk(op.a, op.b, op.c);
+    } else {
+        float s = op.a, c = op.b;
+        float ox = c * r.o.x - s * r.o.z, oz = s * r.o.x + c * r.o.z;
+        float dx = c * r.d.x - s * r.d.z, dz = s * r.d.x + c * r.d.z;
+        r.o.x = ox; r.o.z = oz; r.d.x = dx; r.d.z = dz;
+    }
+}
+__device__ __forceinline__ void apply_chain(const DScene& S, int begin, int count, DRay& r)
+{
+    for (int k = 0; k < count; ++k) apply_op(S.ops[begin + k], r);
+}
+
+/* bare primitive (ray already in the object's frame): t only */
+__device__ __forceinline__ bool prim_t(const DObj& o, const DRay& r, float tMin, float tMax, float& t)
+{
+    switch (o.type) {
+    case RT_OBJ_SPHERE:        return sphere_t(ld3(o.f), o.f[3], r, tMin, tMax, t);
+    case RT_OBJ_MOVING_SPHERE: return sphere_t(moving_centre(o.f, r.time), o.f[8], r, tMin, tMax, t);
+    case RT_OBJ_RECT_XY:
+    case RT_OBJ_RECT_XZ:
+    case RT_OBJ_RECT_YZ:       return rect_any_t(o.type, o.f, r, tMin, tMax, t);
+    case RT_OBJ_BOX: { int face; return box_t(o.f, r, tMin, tMax, t, face); }
+    case RT_OBJ_TRIANGLE:      return triangle_t(o.f, r, tMin, tMax, t);
+    default: return false;
+    }
+}
+
+/* leaf with its own wrapper chain */
+__device__ __forceinline__ bool leaf_t(const DScene& S, const DObj& o, DRay r, float tMin, float tMax, float& t)
+{
+    apply_chain(S, o.op_begin, o.op_count, r);
+    return prim_t(o, r, tMin, tMax, t);
+}
+
+/* ConstantMedium::hit Volumes.cuh:26-49 (ray already in the medium's frame) */
+__device__ __forceinline__ bool medium_t(const DScene& S, const DObj& o, const DRay& r, float tMin, float tMax,
+                                         const PathRng& g, uint32_t bounce, float& t_out)
+{
+    const DObj& b = S.objs[o.child_begin];
+    float t1, t2;
+    if (!leaf_t(S, b, r, -FLT_MAX, FLT_MAX, t1)) return false;
+    if (!leaf_t(S, b, r, t1 + .0001f, FLT_MAX, t2)) return false;
+    if (t1 < tMin) t1 = tMin;
+    if (t2 > tMax) t2 = tMax;
+    if (t1 >= t2) return false;
+    if (t1 < 0) t1 = 0;
+    const float rayLength = length(r.d);
+    const float distanceInsideBoundary = (t2 - t1) * rayLength;
+    const float hitDistance = o.f[0] * logf(rng_medium(g, bounce, o.medium_slot));
+    if (hitDistance > distanceInsideBoundary) return false;
+    t_out = t1 + hitDistance / rayLength;
+    return true;
+}
+
+/* Aabb::hit Aabb.cuh:31-44 against a 32-byte node */
+__device__ __forceinline__ bool node_hit(const rt_bvh_node& n, const DRay& r, float tMin, float tMax)
+{
+    float ta = (n.bmin[0] - r.o.x) / r.d.x, tb = (n.bmax[0] - r.o.x) / r.d.x;
+    tMin = fmaxf(fminf(ta, tb), tMin); tMax = fminf(fmaxf(ta, tb), tMax);
+    if (tMax <= tMin) return false;
+    ta = (n.bmin[1] - r.o.y) / r.d.y; tb = (n.bmax[1] - r.o.y) / r.d.y;
+    tMin = fmaxf(fminf(ta, tb), tMin); tMax = fminf(fmaxf(ta, tb), tMax);
+    if (tMax <= tMin) return false;
+    ta = (n.bmin[2] - r.o.z) / r.d.z; tb = (n.bmax[2] - r.o.z) / r.d.z;
+    tMin = fmaxf(fminf(ta, tb), tMin); tMax = fminf(fmaxf(ta, tb), tMax);
+    return !(tMax <= tMin);
+}
+
+/* ------------------------------------------------------------ closest hit ---- */
+/* `stack` is this lane's column of the block's LDS stack: entry i at stack[i*RT_BLOCK]. */
+template <bool HAS_BVH>
+__device__ __forceinline__ void group_closest(const DScene& S, int gi, const DObj& g, DRay r, float tMin,
+                                              HitLite& best, const PathRng* rng, uint32_t bounce, int* stack)
+{
+    apply_chain(S, g.op_begin, g.op_count, r);
+    if (HAS_BVH && g.bvh_root >= 0) {
+        int sp = 0;
+        int node = g.bvh_root;
+        while (true) {
+            const rt_bvh_node n = S.nodes[node];
+            bool descend = false;
+            if (node_hit(n, r, tMin, best.t)) {
+                if (n.count) {
+                    for (uint32_t i = 0; i < n.count; ++i) {
+                        int oi = S.items[n.left_first + i];
+                        float t;
+                        if (leaf_t(S, S.objs[oi], r, tMin, best.t, t)) { best.t = t; best.obj = oi; best.grp = gi; }
+                    }
+                } else {
+                    /* nearer child first (by box centre along the ray), other one on the stack */
+                    const rt_bvh_node l = S.nodes[n.left_first], rr = S.nodes[n.left_first + 1];
+                    float dl = (0.5f * (l.bmin[0] + l.bmax[0]) - r.o.x) * r.d.x + (0.5f * (l.bmin[1] + l.bmax[1]) - r.o.y) * r.d.y +
+                               (0.5f * (l.bmin[2] + l.bmax[2]) - r.o.z) * r.d.z;
+                    float dr = (0.5f * (rr.bmin[0] + rr.bmax[0]) - r.o.x) * r.d.x + (0.5f * (rr.bmin[1] + rr.bmax[1]) - r.o.y) * r.d.y +
+                               (0.5f * (rr.bmin[2] + rr.bmax[2]) - r.o.z) * r.d.z;
+                    int near = dl <= dr ? (int)n.left_first : (int)n.left_first + 1;
+                    int far = dl <= dr ? (int)n.left_first + 1 : (int)n.left_first;
+                    if (sp < RT_STACK_DEPTH) { stack[sp * RT_BLOCK] = far; ++sp; }
+                    node = near;
+                    descend = true;
+                }
+            }
+            if (!descend) {
+                if (sp == 0) break;
+                --sp;
+                node = stack[sp * RT_BLOCK];
+            }
+        }
+        return;
+    }
+    for (int i = 0; i < g.child_count; ++i) {
+        int oi = g.child_begin + i;
+        const DObj& o = S.objs[oi];
+        float t;
+        if (o.type == RT_OBJ_MEDIUM) {
+            if (rng) {
+                DRay rm = r;
+                apply_chain(S, o.op_begin, o.op_count, rm);
+                if (medium_t(S, o, rm, tMin, best.t, *rng, bounce, t)) { best.t = t; best.obj = oi; best.grp = gi; }
+            }
+        } else if (leaf_t(S, o, r, tMin, best.t, t)) { best.t = t; best.obj = oi; best.grp = gi; }
+    }
+}
+
+/* HitableList::hit over the world (HitableList.cuh:17-32): list order, tMax shrinks */
+template <bool HAS_BVH>
+__device__ __forceinline__ HitLite closest_hit(const DScene& S, const DRay& r, float tMin, float tMax,
+                                               const PathRng* rng, uint32_t bounce, int* stack)
+{
+    HitLite best = {tMax, -1, -1};
+    const DObj& w = S.objs[S.world];
+    if (HAS_BVH && w.bvh_root >= 0) {
+        group_closest<HAS_BVH>(S, -1, w, r, tMin, best, rng, bounce, stack);
+        return best;
+    }
+    for (int i = 0; i < w.child_count; ++i) {
+        int oi = w.child_begin + i;
+        const DObj& o = S.objs[oi];
+        float t;
+        if (o.type == RT_OBJ_GROUP) {
+            group_closest<HAS_BVH>(S, oi, o, r, tMin, best, rng, bounce, stack);
+        } else if (o.type == RT_OBJ_MEDIUM) {
+            if (rng) {
+                DRay rm = r;
+                apply_chain(S, o.op_begin, o.op_count, rm);
+                if (medium_t(S, o, rm, tMin, best.t, *rng, bounce, t)) { best.t = t; best.obj = oi; best.grp = -1; }
+            }
+        } else if (leaf_t(S, o, r, tMin, best.t, t)) { best.t = t; best.obj = oi; best.grp = -1; }
+    }
+    return best;
+}
+
+/* --------------------------------------------------- rebuild the record ---- */
+/* combined wrapper chain of the winner: the group's ops then the leaf's, outermost first */
+struct Chain { int gb, gc, lb, lc; };
+__device__ __forceinline__ const rt_xform_op& chain_op(const DScene& S, const Chain& c, int k)
+{
+    return S.ops[k < c.gc ? c.gb + k : c.lb + (k - c.gc)];
+}
+
+__device__ __forceinline__ void rebuild(const DScene& S, const DRay& world_ray, const HitLite& hl, float tMin, HitRec& h)
+{
+    const DObj& o = S.objs[hl.obj];
+    Chain c = {0, 0, o.op_begin, o.op_count};
+    if (hl.grp >= 0) { c.gb = S.objs[hl.grp].op_begin; c.gc = S.objs[hl.grp].op_count; }
+    const int n = c.gc + c.lc;
+    DRay r = world_ray;
+    for (int k = 0; k < n; ++k) apply_op(chain_op(S, c, k), r);
+
+    const float t = hl.t;
+    h.t = t; h.u = 0.f; h.v = 0.f; h.front = 0;
+    h.material = o.material;
+    h.prim_id = o.prim_id;
+    switch (o.type) {
+    case RT_OBJ_SPHERE: {
+        V3 centre = ld3(o.f);
+        h.p = at(r, t);
+        h.n = (h.p - centre) / o.f[3];
+        V3 q = (h.p - centre) / o.f[3];
+        float phi = atan2f(q.z, q.x);                       /* getSphereUV Sphere.cuh:64-70 */
+        float theta = asinf(q.y);
+        h.u = (float)(1 - (phi + RT_PI_D) / (2 * RT_PI_D));
+        h.v = (float)((theta + RT_PI_D / 2) / RT_PI_D);
+    } break;
+    case RT_OBJ_MOVING_SPHERE: {
+        V3 centre = moving_centre(o.f, r.time);
+        h.p = at(r, t);
+        h.n = (h.p - centre) / o.f[8];
+    } break;
+    case RT_OBJ_RECT_XY: rect_rec<2>(o.f[0], o.f[1], o.f[2], o.f[3], r, t, h); break;
+    case RT_OBJ_RECT_XZ: rect_rec<1>(o.f[0], o.f[1], o.f[2], o.f[3], r, t, h); break;
+    case RT_OBJ_RECT_YZ: rect_rec<0>(o.f[0], o.f[1], o.f[2], o.f[3], r, t, h); break;
+    case RT_OBJ_BOX: {
+        const float* f = o.f;
+        /* re-run the six faces bounded (inclusively) by the winning t: nothing nearer exists, so the
+         * face that survives is the one that produced t in the search */
+        float tt; int face = 0;
+        box_t(f, r, tMin, t, tt, face);
+        switch (face) {
+        case 0: case 1: rect_rec<2>(f[0], f[3], f[1], f[4], r, t, h); break;
+        case 2: case 3: rect_rec<1>(f[0], f[3], f[2], f[5], r, t, h); break;
+        default:        rect_rec<0>(f[1], f[4], f[2], f[5], r, t, h); break;
+        }
+        if (face & 1) h.front = !h.front;                   /* FlipNormals, Surface.cuh:24 */
+    } break;
+    case RT_OBJ_TRIANGLE: {
+        V3 normal = ld3(o.f + 9);
+        h.p = at(r, t);
+        h.n = dot(normal, r.d) > 0 ? -normal : normal;      /* Triangle.cuh:38-41 */
+    } break;
+    default: /* RT_OBJ_MEDIUM, Volumes.cuh:44-46 */
+        h.p = at(r, t);
+        h.n = mk(1.f, 0.f, 0.f);
+        h.front = 1;
+        break;
+    }
+    if (o.flags & RT_OBJ_FLAG_FLIP) h.front = !h.front;
+
+    /* unwind the wrappers, innermost first (Transform.cuh:24, :101-108) */
+    for (int k = n - 1; k >= 0; --k) {
+        const rt_xform_op& op = chain_op(S, c, k);
+        if (op.type == RT_OP_TRANSLATE) {
+            h.p = h.p + mk(op.a, op.b, op.c);
+        } else {
+            /* direction of the ray as this RotateY saw it after rotating: ops 0..k applied */
+            V3 d = world_ray.d;
+            for (int j = 0; j <= k; ++j) {
+                const rt_xform_op& oj = chain_op(S, c, j);
+                if (oj.type == RT_OP_ROTATE_Y) {
+                    float dx = oj.b * d.x - oj.a * d.z, dz = oj.a * d.x + oj.b * d.z;
+                    d.x = dx; d.z = dz;
+                }
+            }
+            float s = op.a, cs = op.b;
+            V3 p = h.p, nn = h.n;
+            p.x = cs * h.p.x + s * h.p.z;
+            p.z = -s * h.p.x + cs * h.p.z;
+            nn.x = cs * h.n.x + s * h.n.z;
+            nn.z = -s * h.n.x + cs * h.n.z;
+            h.p = p;
+            h.front = dot(d, nn) < 0;                        /* setFaceNormal(rotatedR, normal) */
+            h.n = h.front ? nn : -nn;
+        }
+    }
+}
+
+/* --------------------------------------------------------------- textures ---- */
+__device__ __forceinline__ V3 texture_value(const DScene& S, int ti, float u, float v, V3 p)
+{
+    rt_texture t = S.texs[ti];
+    /* CheckerTexture::value Texture.cuh:31-36 (checkers may nest) */
+    for (int guard = 0; guard < 8 && t.type == RT_TEX_CHECKER; ++guard) {
+        float sines = sinf(10 * p.x) * sinf(10 * p.y) * sinf(10 * p.z);
+        t = S.texs[sines < 0 ? t.odd : t.even];
+    }
+    if (t.type == RT_TEX_IMAGE) {                            /* ImageTexture::value Texture.cuh:49-61 */
+        const uint8_t* data = S.image + t.image_offset;
+        int i = (int)(u * t.width);
+        int j = (int)((1 - v) * t.height - .001f);
+        if (i < 0) i = 0;
+        if (j < 0) j = 0;
+        if (i > t.width - 1) i = t.width - 1;
+        if (j > t.height - 1) j = t.height - 1;
+        const uint8_t* px = data + 3 * i + 3 * t.width * j;
+        return mk((int)px[0] / 255.f, (int)px[1] / 255.f, (int)px[2] / 255.f);
+    }
+    return mk(t.colour[0], t.colour[1], t.colour[2]);
+}
+
+/* --------------------------------------------------------------- materials ---- */
+__device__ __forceinline__ V3 random_in_unit_sphere(PathRng& g)                    /* Material.cuh:34-40 */
+{
+    V3 p;
+    do {
+        float a = rng_next(g), b = rng_next(g), c = rng_next(g);
+        p = 2.f * mk(a, b, c) - mk(1.f, 1.f, 1.f);
+    } while (dot(p, p) >= 1.f);
+    return p;
+}
+__device__ __forceinline__ V3 reflect(V3 v, V3 n) { return v - (2.f * dot(v, n)) * n; }   /* Material.cuh:42 */
+__device__ __forceinline__ float schlick(float cosine, float refIdx)              /* Material.cuh:12-17 */
+{
+    float r0 = (1.f - refIdx) / (1.f + refIdx);
+    r0 = r0 * r0;
+    return r0 + (1.f - r0) * powf((1.f - cosine), 5.f);
+}
+__device__ __forceinline__ bool refract(V3 v, V3 n, float niOverNt, V3& refracted)   /* Material.cuh:19-30 */
+{
+    V3 uv = unit(v);
+    float dt = dot(uv, n);
+    float discrim = 1.f - niOverNt * niOverNt * (1 - dt * dt);
+    if (discrim > 0) {
+        refracted = niOverNt * (uv - dt * n) - sqrtf(discrim) * n;
+        return true;
+    }
+    return false;
+}
+
+/* Material::scatter + emitted (Material.cuh:51-144). Returns false when the path ends. */
+__device__ __forceinline__ bool scatter(const DScene& S, const DRay& in, const HitRec& rec, PathRng& g,
+                                        V3& attenuation, DRay& out, V3& emitted)
+{
+    const rt_material m = S.mats[rec.material];
+    emitted = mk(0.f, 0.f, 0.f);
+    attenuation = mk(0.f, 0.f, 0.f);
+    out.o = rec.p;
+    out.time = in.time;
+    switch (m.type) {
+    case RT_MAT_LAMBERT: {
+        V3 target = rec.p + rec.n + random_in_unit_sphere(g);
+        out.d = target - rec.p;
+        attenuation = texture_value(S, m.texture, rec.u, rec.v, rec.p);
+        return true;
+    }
+    case RT_MAT_METAL: {
+        V3 reflected = reflect(unit(in.d), rec.n);
+        out.d = reflected + m.param * random_in_unit_sphere(g);
+        attenuation = texture_value(S, m.texture, 0, 0, rec.p);
+        return dot(out.d, rec.n) > 0.f;
+    }
+    case RT_MAT_GLASS: {
+        float refIdx = m.param;
+        V3 outwardNorm;
+        V3 reflected = reflect(in.d, rec.n);
+        float niOverNt, cosine, reflectProb;
+        attenuation = mk(1.f, 1.f, 1.f);
+        V3 refracted = mk(0.f, 0.f, 0.f);
+        if (dot(in.d, rec.n) > 0.f) {
+            outwardNorm = -rec.n;
+            niOverNt = refIdx;
+            cosine = dot(in.d, rec.n) / length(in.d);
+            cosine = sqrtf(1.f - refIdx * refIdx * (1 - cosine * cosine));
+        } else {
+            outwardNorm = rec.n;
+            niOverNt = 1.f / refIdx;
+            cosine = -dot(in.d, rec.n) / length(in.d);
+        }
+        if (refract(in.d, outwardNorm, niOverNt, refracted)) reflectProb = schlick(cosine, refIdx);
+        else reflectProb = 1.f;
+        out.d = rng_next(g) < reflectProb ? reflected : refracted;
+        return true;
+    }
+    case RT_MAT_LIGHT:
+        emitted = texture_value(S, m.texture, rec.u, rec.v, rec.p);
+        return false;
+    default: /* Isotropic: time resets to 0 (Material.cuh:140) */
+        out.d = random_in_unit_sphere(g);
+        out.time = 0.f;
+        attenuation = texture_value(S, m.texture, rec.u, rec.v, rec.p);
+        return true;
+    }
+}
+
+/* ------------------------------------------------------------------ camera ---- */
+__device__ __forceinline__ DRay generate_ray(const rt_camera& c, float s, float t, PathRng& g)   /* Camera.cuh:40-46 */
+{
+    V3 p;
+    do {                                                                             /* randomInUnitDisk :12-18 */
+        float a = rng_next(g), b = rng_next(g);
+        p = 2.0f * mk(a, b, 0.f) - mk(1.f, 1.f, 0.f);
+    } while (dot(p, p) > 1.f);
+    V3 rd = c.lens_radius * p;
+    V3 offset = rd.x * ld3(c.u) + rd.y * ld3(c.v);
+    float time = c.time0 + rng_next(g) * (c.time1 - c.time0);
+    DRay r;
+    r.o = ld3(c.origin) + offset;
+    r.d = ld3(c.lower_left) + s * ld3(c.horizontal) + t * ld3(c.vertical) - ld3(c.origin) - offset;
+    r.time = time;
+    return r;
+}
+__device__ __forceinline__ DRay primary_ray(const rt_camera& c, float s, float t)
+{
+    DRay r;
+    V3 offset = mk(0.f, 0.f, 0.f);
+    r.o = ld3(c.origin) + offset;
+    r.d = ld3(c.lower_left) + s * ld3(c.horizontal) + t * ld3(c.vertical) - ld3(c.origin) - offset;
+    r.time = c.time0;
+    return r;
+}
+
+#endif

@@ -1,0 +1,156 @@
+/*
+ * rt_host.cpp — error string, scene validation, object packing, image output.
+ */
+#include "rt_host.h"
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "../../include/rt_api.h"
+
+static thread_local std::string g_err;
+void rt_set_error(const std::string& msg) { g_err = msg; }
+extern "C" const char* rt_last_error(void) { return g_err.c_str(); }
+
+static int bvh_depth_of(const rt_flat_scene* s, int root, int limit, bool& ok, std::vector<uint8_t>& seen)
+{
+    /* iterative DFS; every node may be reached once (a DAG or cycle is refused) */
+    struct E { int node, depth; };
+    std::vector<E> st;
+    st.push_back({root, 1});
+    int deepest = 0;
+    while (!st.empty()) {
+        E e = st.back();
+        st.pop_back();
+        if (e.node < 0 || e.node >= s->n_bvh_nodes || seen[e.node] || e.depth > limit) { ok = false; return 0; }
+        seen[e.node] = 1;
+        if (e.depth > deepest) deepest = e.depth;
+        const rt_bvh_node& n = s->bvh_nodes[e.node];
+        if (n.count) {
+            if ((uint64_t)n.left_first + n.count > (uint64_t)s->n_bvh_items) { ok = false; return 0; }
+        } else {
+            if ((uint64_t)n.left_first + 1 >= (uint64_t)s->n_bvh_nodes) { ok = false; return 0; }
+            st.push_back({(int)n.left_first, e.depth + 1});
+            st.push_back({(int)n.left_first + 1, e.depth + 1});
+        }
+    }
+    return deepest;
+}
+
+bool rt_validate_scene(const rt_flat_scene* s, std::string& why, int* bvh_depth)
+{
+    auto bad = [&](const char* m) { why = m; return false; };
+    if (bvh_depth) *bvh_depth = 0;
+    if (s->n_objects < 1 || !s->objects) return bad("no objects");
+    if (s->world < 0 || s->world >= s->n_objects || s->objects[s->world].type != RT_OBJ_GROUP) return bad("world is not a group");
+    if ((s->n_ops && !s->ops) || (s->n_materials && !s->materials) || (s->n_textures && !s->textures) ||
+        (s->n_image_bytes && !s->image_bytes) || (s->n_bvh_nodes && !s->bvh_nodes) || (s->n_bvh_items && !s->bvh_items))
+        return bad("null table");
+    for (int i = 0; i < s->n_textures; ++i) {
+        const rt_texture& t = s->textures[i];
+        if (t.type == RT_TEX_CHECKER) {
+            if (t.even < 0 || t.even >= s->n_textures || t.odd < 0 || t.odd >= s->n_textures) return bad("checker child out of range");
+        } else if (t.type == RT_TEX_IMAGE) {
+            if (t.width <= 0 || t.height <= 0) return bad("image texture without extent");
+            if (t.image_offset + (uint64_t)t.width * (uint64_t)t.height * 3u > s->n_image_bytes) return bad("image texture out of range");
+        } else if (t.type != RT_TEX_CONSTANT) return bad("unknown texture type");
+    }
+    for (int i = 0; i < s->n_materials; ++i) {
+        const rt_material& m = s->materials[i];
+        if (m.type < RT_MAT_LAMBERT || m.type > RT_MAT_ISOTROPIC) return bad("unknown material type");
+        if (m.type != RT_MAT_GLASS && (m.texture < 0 || m.texture >= s->n_textures)) return bad("material texture out of range");
+    }
+    for (int i = 0; i < s->n_ops; ++i)
+        if (s->ops[i].type != RT_OP_TRANSLATE && s->ops[i].type != RT_OP_ROTATE_Y) return bad("unknown transform op");
+    for (int i = 0; i < s->n_bvh_items; ++i) {
+        int oi = s->bvh_items[i];
+        if (oi < 0 || oi >= s->n_objects) return bad("BVH item out of range");
+        int ty = s->objects[oi].type;
+        if (ty == RT_OBJ_GROUP || ty == RT_OBJ_MEDIUM) return bad("BVH item is not a surface");
+    }
+    std::vector<uint8_t> seen((size_t)s->n_bvh_nodes, 0);
+    int deepest = 0;
+    for (int i = 0; i < s->n_objects; ++i) {
+        const rt_object& o = s->objects[i];
+        if (o.type < RT_OBJ_SPHERE || o.type > RT_OBJ_GROUP) return bad("unknown object type");
+        if (o.op_count < 0 || o.op_begin < 0 || (int64_t)o.op_begin + o.op_count > s->n_ops) return bad("op chain out of range");
+        if (o.op_count > 8) return bad("op chain longer than 8");
+        if (o.type == RT_OBJ_GROUP) {
+            if (o.child_count < 0 || o.child_begin < 0 || (int64_t)o.child_begin + o.child_count > s->n_objects) return bad("group children out of range");
+            for (int k = 0; k < o.child_count; ++k) {
+                const rt_object& ch = s->objects[o.child_begin + k];
+                if (ch.type == RT_OBJ_GROUP && i != s->world) return bad("group nested below a group");
+            }
+            if (o.bvh_root >= 0) {
+                bool ok = true;
+                int d = bvh_depth_of(s, o.bvh_root, 4096, ok, seen);
+                if (!ok) return bad("malformed BVH");
+                if (d > deepest) deepest = d;
+            }
+        } else {
+            if (o.material < 0 || o.material >= s->n_materials) return bad("object material out of range");
+            if (o.type == RT_OBJ_MEDIUM) {
+                if (o.child_begin < 0 || o.child_begin >= s->n_objects) return bad("medium boundary out of range");
+                int bt = s->objects[o.child_begin].type;
+                if (bt == RT_OBJ_GROUP || bt == RT_OBJ_MEDIUM) return bad("medium boundary is not a surface");
+                if (o.medium_slot < 0) return bad("medium without a slot");
+            }
+        }
+    }
+    if (bvh_depth) *bvh_depth = deepest;
+    return true;
+}
+
+void rt_pack_objects(const rt_flat_scene* s, DObj* out)
+{
+    for (int i = 0; i < s->n_objects; ++i) {
+        const rt_object& o = s->objects[i];
+        DObj d;
+        std::memset(&d, 0, sizeof d);
+        d.type = o.type; d.material = o.material; d.op_begin = o.op_begin; d.op_count = o.op_count;
+        d.child_begin = o.child_begin; d.child_count = o.child_count; d.bvh_root = o.bvh_root;
+        d.medium_slot = o.medium_slot; d.prim_id = o.prim_id; d.flags = o.flags;
+        for (int k = 0; k < 10; ++k) d.f[k] = o.f[k];
+        if (o.type == RT_OBJ_TRIANGLE) {
+            const float* f = o.f;
+            float e1[3] = {f[3] - f[0], f[4] - f[1], f[5] - f[2]};
+            float e2[3] = {f[6] - f[0], f[7] - f[1], f[8] - f[2]};
+            float c[3] = {(e1[1] * e2[2] - e1[2] * e2[1]), (-(e1[0] * e2[2] - e1[2] * e2[0])), (e1[0] * e2[1] - e1[1] * e2[0])};
+            float len = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+            float n[3] = {c[0] / len, c[1] / len, c[2] / len};
+            float z[3] = {0.f - f[0], 0.f - f[1], 0.f - f[2]};
+            d.f[9] = n[0]; d.f[10] = n[1]; d.f[11] = n[2];
+            d.f[12] = z[0] * n[0] + z[1] * n[1] + z[2] * n[2];
+        }
+        out[i] = d;
+    }
+}
+
+extern "C" int rt_quantise_rgb8(const float* rgb, int width, int height, uint8_t* out)
+{
+    if (!rgb || !out || width <= 0 || height <= 0) { rt_set_error("rt_quantise_rgb8: bad arguments"); return RT_ERR_ARG; }
+    size_t index = 0;
+    for (int j = height - 1; j >= 0; j--)
+        for (int i = 0; i < width; i++) {
+            const float* px = rgb + 3 * ((size_t)j * width + i);
+            for (int k = 0; k < 3; ++k) {
+                double v = 255.99 * px[k];
+                int q = v != v ? 0 : (v < 0 ? 0 : (v > 255 ? 255 : (int)v));
+                out[index++] = (uint8_t)q;
+            }
+        }
+    return RT_OK;
+}
+
+extern "C" int rt_write_ppm(const char* path, const uint8_t* rgb8, int width, int height)
+{
+    if (!path || !rgb8 || width <= 0 || height <= 0) { rt_set_error("rt_write_ppm: bad arguments"); return RT_ERR_ARG; }
+    FILE* f = std::fopen(path, "wb");
+    if (!f) { rt_set_error(std::string("rt_write_ppm: cannot open ") + path); return RT_ERR_ARG; }
+    std::fprintf(f, "P6\n%d %d\n255\n", width, height);
+    size_t n = (size_t)width * height * 3;
+    bool ok = std::fwrite(rgb8, 1, n, f) == n;
+    ok = std::fclose(f) == 0 && ok;
+    if (!ok) { rt_set_error("rt_write_ppm: short write"); return RT_ERR_ARG; }
+    return RT_OK;
+}

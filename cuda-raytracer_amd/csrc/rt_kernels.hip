@@ -1,0 +1,437 @@
+/*
+ * rt_kernels.hip — HIP kernels for gfx950 and the device half of the C ABI (include/rt_api.h).
+ *
+ * render_kernel replaces the reference's `render` (main.cu:125-198).  The reference runs one
+ * thread per pixel and lets a 32-lane warp wait for its slowest lane through numSamples x <=100
+ * bounces.  Here a 64-lane wave owns an 8x8 pixel tile and every lane is a small state machine:
+ * the moment its path ends it starts its pixel's next sample, so the wave's closest-hit step
+ * always runs with (almost) all lanes live, and the per-pixel sum stays in registers until the
+ * lane has finished its sample range — no queues in HBM, no atomics, a fixed summation order.
+ * For scenes whose tables sit in the scalar cache (Cornell: 9 objects) the kernel is bound by
+ * VALU issue; DESIGN.md has the numbers and why a queue-based wavefront would instead be bound
+ * by its own queue traffic there.
+ */
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/rt_api.h"
+#include "rt_device.h"
+#include "rt_host.h"
+
+/* ------------------------------------------------------------------ kernels -- */
+template <bool HAS_BVH>
+__global__ __launch_bounds__(RT_BLOCK) void trace_rays_kernel(DScene S, int n, const float* __restrict__ rays,
+                                                               float tmin, float tmax, rt_hit_record* __restrict__ out)
+{
+    __shared__ int stack_mem[HAS_BVH ? RT_STACK_DEPTH * RT_BLOCK : 1];
+    int* stack = stack_mem + (HAS_BVH ? threadIdx.x : 0);
+    int i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float* q = rays + 7 * (size_t)i;
+    DRay r;
+    r.o = mk(q[0], q[1], q[2]);
+    r.d = mk(q[3], q[4], q[5]);
+    r.time = q[6];
+    HitLite hl = closest_hit<HAS_BVH>(S, r, tmin, tmax, nullptr, 0u, stack);
+    rt_hit_record o;
+    memset(&o, 0, sizeof o);
+    o.prim = -1;
+    if (hl.obj >= 0) {
+        HitRec h;
+        rebuild(S, r, hl, tmin, h);
+        o.hit = 1; o.prim = h.prim_id; o.t = h.t; o.u = h.u; o.v = h.v;
+        o.p[0] = h.p.x; o.p[1] = h.p.y; o.p[2] = h.p.z;
+        o.n[0] = h.n.x; o.n[1] = h.n.y; o.n[2] = h.n.z;
+        o.front_face = h.front; o.material = h.material;
+    }
+    out[i] = o;
+}
+
+/* lane -> pixel inside a 16x16 block tile; each wave covers an 8x8 sub-tile */
+__device__ __forceinline__ void tile_pixel(int W, int tile, int tid, int& i, int& j)
+{
+    int tiles_x = (W + 15) >> 4;
+    int tx = tile % tiles_x, ty = tile / tiles_x;
+    int lx = (tid & 7) | (((tid >> 6) & 1) << 3);
+    int ly = ((tid >> 3) & 7) | (((tid >> 7) & 1) << 3);
+    i = tx * 16 + lx;
+    j = ty * 16 + ly;
+}
+
+/* blocks b and b+8 share an XCD (and its L2): hand each XCD a contiguous run of tiles */
+__device__ __forceinline__ int xcd_tile(int b, int nb)
+{
+    int q = nb >> 3, r = nb & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+template <bool HAS_BVH>
+__global__ __launch_bounds__(RT_BLOCK) void trace_primary_kernel(DScene S, int W, int H, float s_off, float t_off,
+                                                                  int32_t* __restrict__ prim, float* __restrict__ t_out)
+{
+    __shared__ int stack_mem[HAS_BVH ? RT_STACK_DEPTH * RT_BLOCK : 1];
+    int* stack = stack_mem + (HAS_BVH ? threadIdx.x : 0);
+    int i, j;
+    tile_pixel(W, xcd_tile(blockIdx.x, gridDim.x), threadIdx.x, i, j);
+    if (i >= W || j >= H) return;
+    float u = float(i + s_off) / float(W);
+    float v = float(j + t_off) / float(H);
+    DRay r = primary_ray(S.cam, u, v);
+    HitLite hl = closest_hit<HAS_BVH>(S, r, .001f, FLT_MAX, nullptr, 0u, stack);
+    size_t px = (size_t)j * W + i;
+    prim[px] = hl.obj >= 0 ? S.objs[hl.obj].prim_id : -1;
+    t_out[px] = hl.obj >= 0 ? hl.t : 0.f;
+}
+
+template <bool HAS_BVH, int BG>
+__global__ __launch_bounds__(RT_BLOCK) void render_kernel(DScene S, int W, int H, uint32_t s_begin, uint32_t s_end,
+                                                           uint32_t k0, uint32_t k1, int max_depth,
+                                                           float* __restrict__ accum,
+                                                           unsigned long long* __restrict__ counters)
+{
+    __shared__ int stack_mem[HAS_BVH ? RT_STACK_DEPTH * RT_BLOCK : 1];
+    int* stack = stack_mem + (HAS_BVH ? threadIdx.x : 0);
+    int i, j;
+    tile_pixel(W, xcd_tile(blockIdx.x, gridDim.x), threadIdx.x, i, j);
+    const bool valid = i < W && j < H;
+    const uint32_t pixel = (uint32_t)(j * W + i);
+
+    V3 sum = mk(0.f, 0.f, 0.f);
+    uint32_t s = valid ? s_begin : s_end;
+    bool alive = false;
+    DRay ray = {mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f), 0.f};
+    V3 att = mk(1.f, 1.f, 1.f), emi = mk(0.f, 0.f, 0.f);
+    int depth = 0;
+    uint32_t n_rays = 0;
+    PathRng g;
+    rng_start(g, k0, k1, pixel, 0u);
+
+    while (true) {
+        if (!alive && s < s_end) {
+            /* main.cu:185-188: jittered pixel position, camera ray, fresh path */
+            rng_start(g, k0, k1, pixel, s);
+            float u = float(i + rng_next(g)) / float(W);
+            float v = float(j + rng_next(g)) / float(H);
+            ray = generate_ray(S.cam, u, v, g);
+            att = mk(1.f, 1.f, 1.f);
+            emi = mk(0.f, 0.f, 0.f);
+            depth = 0;
+            alive = true;
+            ++s;
+        }
+        if (__ballot(alive) == 0ull) break;
+        if (alive) {
+            /* one iteration of colour() / colourUnlit(), main.cu:53-70 / :77-98 */
+            HitLite hl = closest_hit<HAS_BVH>(S, ray, .001f, FLT_MAX, &g, (uint32_t)depth, stack);
+            ++n_rays;
+            V3 result;
+            bool done;
+            if (hl.obj >= 0) {
+                HitRec rec;
+                rebuild(S, ray, hl, .001f, rec);
+                V3 attenuation, emitted;
+                DRay scattered;
+                if (scatter(S, ray, rec, g, attenuation, scattered, emitted)) {
+                    att = att * attenuation;
+                    if (BG == RT_BG_BLACK) emi = emi + emitted * att;
+                    ray = scattered;
+                    done = false;
+                    result = mk(0.f, 0.f, 0.f);
+                } else {
+                    result = BG == RT_BG_BLACK ? emi + emitted * att : mk(0.f, 0.f, 0.f);
+                    done = true;
+                }
+            } else {
+                if (BG == RT_BG_BLACK) result = emi;
+                else {
+                    V3 ud = unit(ray.d);
+                    float t = .5f * (ud.y + 1.f);
+                    V3 c = (1.f - t) * mk(1.f, 1.f, 1.f) + t * mk(.5f, .7f, 1.f);
+                    result = att * c;
+                }
+                done = true;
+            }
+            ++depth;
+            if (!done && depth >= max_depth) {
+                result = BG == RT_BG_BLACK ? emi : mk(0.f, 0.f, 0.f);
+                done = true;
+            }
+            if (done) {
+                sum = sum + result;
+                alive = false;
+            }
+        }
+    }
+    if (valid) {
+        float* a = accum + 3 * (size_t)pixel;
+        a[0] += sum.x; a[1] += sum.y; a[2] += sum.z;
+    }
+    /* ray / sample counters: one atomic per wave */
+    unsigned long long r = n_rays, p = valid ? (unsigned long long)(s_end - s_begin) : 0ull;
+    for (int off = 32; off > 0; off >>= 1) {
+        r += __shfl_down(r, off);
+        p += __shfl_down(p, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&counters[0], r);
+        atomicAdd(&counters[1], p);
+    }
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void resolve_kernel(const float* __restrict__ accum, size_t n, float inv_spp,
+                                                           int gamma, float* __restrict__ rgb)
+{
+    size_t i = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float c = accum[i] * inv_spp;          /* outCol /= float(numSamples): multiply by reciprocal */
+    rgb[i] = gamma ? sqrtf(c) : c;
+}
+
+/* --------------------------------------------------------------------- host -- */
+#define HIPCHK(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            rt_set_error(std::string("HIP error ") + hipGetErrorString(e_) + " at " #expr);    \
+            return RT_ERR_HIP;                                                                 \
+        }                                                                                      \
+    } while (0)
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool have_scene = false;
+    bool has_bvh = false;
+    DScene ds;
+    void* d_objs = nullptr;  void* d_ops = nullptr;   void* d_mats = nullptr; void* d_texs = nullptr;
+    void* d_image = nullptr; void* d_nodes = nullptr; void* d_items = nullptr;
+    unsigned long long* d_counters = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    /* render launches whose event pair has not been read back yet are timed lazily */
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double render_ms = 0.0, last_ms = 0.0;
+    uint32_t launches = 0;
+};
+
+static void free_scene(rt_ctx* c)
+{
+    void** ptrs[] = {&c->d_objs, &c->d_ops, &c->d_mats, &c->d_texs, &c->d_image, &c->d_nodes, &c->d_items};
+    for (void** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    c->have_scene = false;
+}
+
+extern "C" int rt_ctx_create(int device, void* stream, rt_ctx** out)
+{
+    if (!out) { rt_set_error("rt_ctx_create: null out"); return RT_ERR_ARG; }
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) { rt_set_error("rt_ctx_create: no such device"); return RT_ERR_ARG; }
+    HIPCHK(hipSetDevice(device));
+    rt_ctx* c = new rt_ctx();
+    c->device = device;
+    if (stream) c->stream = (hipStream_t)stream;
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; rt_set_error("hipStreamCreate failed"); return RT_ERR_HIP; }
+        c->own_stream = true;
+    }
+    if (hipMalloc((void**)&c->d_counters, 2 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemsetAsync(c->d_counters, 0, 2 * sizeof(unsigned long long), c->stream) != hipSuccess) {
+        rt_ctx_destroy(c);
+        rt_set_error("counter allocation failed");
+        return RT_ERR_HIP;
+    }
+    *out = c;
+    return RT_OK;
+}
+
+extern "C" void rt_ctx_destroy(rt_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    free_scene(c);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+template <class T>
+static int upload(rt_ctx* c, void** dst, const T* src, size_t n)
+{
+    size_t bytes = (n ? n : 1) * sizeof(T);
+    HIPCHK(hipMalloc(dst, bytes));
+    if (n) HIPCHK(hipMemcpyAsync(*dst, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return RT_OK;
+}
+
+extern "C" int rt_scene_upload(rt_ctx* c, const rt_flat_scene* s)
+{
+    if (!c || !s) { rt_set_error("rt_scene_upload: null argument"); return RT_ERR_ARG; }
+    std::string why;
+    int bvh_depth = 0;
+    if (!rt_validate_scene(s, why, &bvh_depth)) { rt_set_error("rt_scene_upload: invalid scene: " + why); return RT_ERR_ARG; }
+    if (bvh_depth > RT_STACK_DEPTH) { rt_set_error("rt_scene_upload: BVH deeper than the traversal stack"); return RT_ERR_UNSUPPORTED; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    free_scene(c);
+
+    std::vector<DObj> objs((size_t)s->n_objects);
+    rt_pack_objects(s, objs.data());
+    int rc;
+    if ((rc = upload(c, &c->d_objs, objs.data(), objs.size()))) return rc;
+    if ((rc = upload(c, &c->d_ops, s->ops, (size_t)s->n_ops))) return rc;
+    if ((rc = upload(c, &c->d_mats, s->materials, (size_t)s->n_materials))) return rc;
+    if ((rc = upload(c, &c->d_texs, s->textures, (size_t)s->n_textures))) return rc;
+    if ((rc = upload(c, &c->d_image, s->image_bytes, (size_t)s->n_image_bytes))) return rc;
+    if ((rc = upload(c, &c->d_nodes, s->bvh_nodes, (size_t)s->n_bvh_nodes))) return rc;
+    if ((rc = upload(c, &c->d_items, s->bvh_items, (size_t)s->n_bvh_items))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream)); /* objs is a local */
+    c->ds.objs = (const DObj*)c->d_objs;
+    c->ds.ops = (const rt_xform_op*)c->d_ops;
+    c->ds.mats = (const rt_material*)c->d_mats;
+    c->ds.texs = (const rt_texture*)c->d_texs;
+    c->ds.image = (const uint8_t*)c->d_image;
+    c->ds.nodes = (const rt_bvh_node*)c->d_nodes;
+    c->ds.items = (const int32_t*)c->d_items;
+    c->ds.world = s->world;
+    c->ds.n_media = s->n_media;
+    c->ds.cam = s->camera;
+    c->has_bvh = s->n_bvh_nodes > 0;
+    c->have_scene = true;
+    return RT_OK;
+}
+
+static int need_scene(rt_ctx* c, const char* who)
+{
+    if (!c) { rt_set_error(std::string(who) + ": null context"); return RT_ERR_ARG; }
+    if (!c->have_scene) { rt_set_error(std::string(who) + ": no scene uploaded"); return RT_ERR_NO_SCENE; }
+    return RT_OK;
+}
+
+extern "C" int rt_trace_rays(rt_ctx* c, int n, const float* rays, float tmin, float tmax, rt_hit_record* out)
+{
+    int rc = need_scene(c, "rt_trace_rays");
+    if (rc) return rc;
+    if (n < 0 || (n && (!rays || !out))) { rt_set_error("rt_trace_rays: bad arguments"); return RT_ERR_ARG; }
+    if (n == 0) return RT_OK;
+    HIPCHK(hipSetDevice(c->device));
+    dim3 grid((unsigned)((n + RT_BLOCK - 1) / RT_BLOCK));
+    if (c->has_bvh) trace_rays_kernel<true><<<grid, RT_BLOCK, 0, c->stream>>>(c->ds, n, rays, tmin, tmax, out);
+    else trace_rays_kernel<false><<<grid, RT_BLOCK, 0, c->stream>>>(c->ds, n, rays, tmin, tmax, out);
+    HIPCHK(hipGetLastError());
+    return RT_OK;
+}
+
+static bool frame_ok(int w, int h) { return w > 0 && h > 0 && (long long)w * h <= (1ll << 30); }
+static unsigned n_tiles(int w, int h) { return (unsigned)(((w + 15) / 16) * ((h + 15) / 16)); }
+
+extern "C" int rt_trace_primary(rt_ctx* c, int w, int h, float s_off, float t_off, int32_t* prim, float* t)
+{
+    int rc = need_scene(c, "rt_trace_primary");
+    if (rc) return rc;
+    if (!frame_ok(w, h) || !prim || !t) { rt_set_error("rt_trace_primary: bad arguments"); return RT_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    dim3 grid(n_tiles(w, h));
+    if (c->has_bvh) trace_primary_kernel<true><<<grid, RT_BLOCK, 0, c->stream>>>(c->ds, w, h, s_off, t_off, prim, t);
+    else trace_primary_kernel<false><<<grid, RT_BLOCK, 0, c->stream>>>(c->ds, w, h, s_off, t_off, prim, t);
+    HIPCHK(hipGetLastError());
+    return RT_OK;
+}
+
+extern "C" int rt_render_accumulate(rt_ctx* c, int w, int h, uint32_t s0, uint32_t s1, uint64_t seed, int max_depth,
+                                    int background, float* accum)
+{
+    int rc = need_scene(c, "rt_render_accumulate");
+    if (rc) return rc;
+    if (!frame_ok(w, h) || !accum || s1 < s0 || max_depth < 0 || (background != RT_BG_BLACK && background != RT_BG_SKY)) {
+        rt_set_error("rt_render_accumulate: bad arguments");
+        return RT_ERR_ARG;
+    }
+    if (s1 == s0) return RT_OK;
+    HIPCHK(hipSetDevice(c->device));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    dim3 grid(n_tiles(w, h));
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    HIPCHK(hipEventRecord(e0, c->stream));
+#define RT_LAUNCH(B, G) render_kernel<B, G><<<grid, RT_BLOCK, 0, c->stream>>>(c->ds, w, h, s0, s1, k0, k1, max_depth, accum, c->d_counters)
+    if (c->has_bvh) { if (background == RT_BG_BLACK) RT_LAUNCH(true, RT_BG_BLACK); else RT_LAUNCH(true, RT_BG_SKY); }
+    else            { if (background == RT_BG_BLACK) RT_LAUNCH(false, RT_BG_BLACK); else RT_LAUNCH(false, RT_BG_SKY); }
+#undef RT_LAUNCH
+    hipError_t le = hipGetLastError();
+    HIPCHK(hipEventRecord(e1, c->stream));
+    c->pending.push_back({e0, e1});
+    if (le != hipSuccess) { rt_set_error(std::string("render launch failed: ") + hipGetErrorString(le)); return RT_ERR_HIP; }
+    return RT_OK;
+}
+
+extern "C" int rt_resolve(rt_ctx* c, const float* accum, int w, int h, uint32_t spp, int gamma, float* rgb)
+{
+    if (!c || !frame_ok(w, h) || !accum || !rgb || spp == 0) { rt_set_error("rt_resolve: bad arguments"); return RT_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    size_t n = (size_t)w * h * 3;
+    float inv = 1.0f / float(spp);
+    resolve_kernel<<<dim3((unsigned)((n + RT_BLOCK - 1) / RT_BLOCK)), RT_BLOCK, 0, c->stream>>>(accum, n, inv, gamma, rgb);
+    HIPCHK(hipGetLastError());
+    return RT_OK;
+}
+
+extern "C" int rt_synchronize(rt_ctx* c)
+{
+    if (!c) { rt_set_error("rt_synchronize: null context"); return RT_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+static int drain_events(rt_ctx* c)
+{
+    for (auto& p : c->pending) {
+        float ms = 0.f;
+        HIPCHK(hipEventSynchronize(p.second));
+        HIPCHK(hipEventElapsedTime(&ms, p.first, p.second));
+        c->render_ms += ms;
+        c->last_ms = ms;
+        c->launches++;
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    c->pending.clear();
+    return RT_OK;
+}
+
+extern "C" int rt_get_counters(rt_ctx* c, rt_counters* out)
+{
+    if (!c || !out) { rt_set_error("rt_get_counters: null argument"); return RT_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int rc = drain_events(c);
+    if (rc) return rc;
+    unsigned long long h[2] = {0, 0};
+    HIPCHK(hipMemcpy(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
+    out->rays = h[0];
+    out->samples = h[1];
+    out->render_ms = c->render_ms;
+    out->last_render_ms = c->last_ms;
+    out->render_launches = c->launches;
+    out->pad = 0;
+    return RT_OK;
+}
+
+extern "C" int rt_reset_counters(rt_ctx* c)
+{
+    if (!c) { rt_set_error("rt_reset_counters: null context"); return RT_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int rc = drain_events(c);
+    if (rc) return rc;
+    HIPCHK(hipMemset(c->d_counters, 0, 2 * sizeof(unsigned long long)));
+    c->render_ms = c->last_ms = 0.0;
+    c->launches = 0;
+    return RT_OK;
+}

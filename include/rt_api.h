@@ -1,0 +1,119 @@
+/*
+ * rt_api.h — C ABI of librt_amd.so, the MI355X path tracer.
+ *
+ * The reference has no library boundary: its host side is one function,
+ *     Vector3* gpuRender(int width,int height,int numSamples,int tx,int ty,int gpuId)
+ * (reference raytracer/main.cu:553-620), which allocates, builds the world in a
+ * <<<1,1>>> kernel, renders and frees.  The entry points below are what a binding for that
+ * path calls instead; each one names the piece of gpuRender / main.cu it replaces.
+ * INTEGRATION.md shows the drop-in gpuRender() written over them.
+ *
+ * Conventions: every function returns 0 on success or a negative rt_status; nothing
+ * throws or exits (the reference prints and exit(99)s, main.cu:33-44).  rt_last_error()
+ * gives the message of the calling thread's last failure.  Pointers named *_dev are
+ * device (HBM) pointers on the context's device; everything else is host memory.
+ * A context is bound to one device and one HIP stream and is not thread-safe; use one
+ * context per GPU (the reference uses one host thread per GPU, main.cu:655-656).
+ */
+#ifndef RT_API_H
+#define RT_API_H
+#include <stdint.h>
+#include "rt_scene.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum rt_status {
+    RT_OK            =  0,
+    RT_ERR_ARG       = -1,   /* bad argument / scene fails validation */
+    RT_ERR_HIP       = -2,   /* a HIP runtime call failed */
+    RT_ERR_UNSUPPORTED = -3, /* scene graph the flat tables cannot express */
+    RT_ERR_NO_SCENE  = -4
+};
+
+typedef struct rt_ctx   rt_ctx;
+typedef struct rt_scene rt_scene;
+
+/* closest-hit record, the Intersect of Hitable.cuh:10-22 with the matPtr replaced by ids */
+typedef struct rt_hit_record {
+    int32_t hit;
+    int32_t prim;          /* rt_object::prim_id, -1 on miss */
+    float   t, u, v;
+    float   p[3];
+    float   n[3];
+    int32_t front_face;
+    int32_t material;
+} rt_hit_record;           /* 52 bytes */
+
+typedef struct rt_counters {
+    uint64_t rays;            /* closest-hit queries issued by render calls since the last reset */
+    uint64_t samples;         /* camera paths started */
+    double   render_ms;       /* HIP-event time of those render kernels, summed */
+    double   last_render_ms;  /* HIP-event time of the most recent render kernel */
+    uint32_t render_launches;
+    uint32_t pad;
+} rt_counters;
+
+const char* rt_last_error(void);
+
+/* ---- scenes (replaces createWorld<<<1,1>>> + the sceneN functions, main.cu:203-539) ---- */
+/* Built-in scenes written against the scene-description API (cuda-raytracer_amd/api/):
+ *   "cornell"         Cornell box                      (the reference's active scene, main.cu:278-306)
+ *   "cornell_smoke"   same, boxes as ConstantMedium    (main.cu:296-297)
+ *   "random_spheres"  ~488 spheres, sky integrator     (main.cu:203-248; procedural image texture)
+ *   "lit_sphere"      RotateY'd spheres + emissive     (main.cu:251-275)
+ *   "bvh_boxes"       BvhNode of boxes + light sphere  (main.cu:309-352)
+ *   "cornell_cluster" glass box + instanced sphere BVH (main.cu:417-451)
+ *   "final"           Next-Week final scene; param = boxes per side (0 -> 20)   (main.cu:355-414)
+ *   "tri_mesh"        synthetic triangle mesh + light; param = triangle count (0 -> 1,000,000)
+ *   "kat"             one of every primitive / wrapper, for parity tests
+ * C++ callers with their own scene functions use rt::lower() (csrc/lower.h) and
+ * rt_scene_from_flat() instead. */
+int  rt_scene_create_builtin(const char* name, int width, int height, int param, rt_scene** out);
+/* deep-copies caller-owned tables */
+int  rt_scene_from_flat(const rt_flat_scene* flat, rt_scene** out);
+const rt_flat_scene* rt_scene_flat(const rt_scene* s);
+int  rt_scene_default_background(const rt_scene* s);   /* RT_BG_* the scene is meant to be lit with */
+void rt_scene_destroy(rt_scene* s);
+
+/* ---- context (replaces cudaSetDevice + the allocations of gpuRender, main.cu:555-595) ---- */
+/* stream: a hipStream_t to run on (e.g. torch's current stream) or NULL for a private one */
+int  rt_ctx_create(int device, void* stream, rt_ctx** out);
+void rt_ctx_destroy(rt_ctx* c);
+/* validates every index in the tables, then copies them to the device */
+int  rt_scene_upload(rt_ctx* c, const rt_flat_scene* flat);
+
+/* ---- closest hit (the body of colour()'s loop, main.cu:56; HitableList::hit) ---- */
+/* n rays of 7 floats (origin, direction, time); media are ignored (no RNG in a bare query) */
+int  rt_trace_rays(rt_ctx* c, int n, const float* rays7_dev, float tmin, float tmax, rt_hit_record* out_dev);
+/* pinhole-centre primary ray of every pixel: u=(i+s_off)/W, v=(j+t_off)/H, lens offset 0,
+ * time=time0; tmin=.001f, tmax=FLT_MAX.  prim_dev/t_dev are W*H, row 0 = bottom. */
+int  rt_trace_primary(rt_ctx* c, int width, int height, float s_off, float t_off,
+                      int32_t* prim_dev, float* t_dev);
+
+/* ---- render (replaces renderInit + render, main.cu:108-198, minus the mean and sqrt) ---- */
+/* accum_dev[3*(j*W+i)+c] += sum over samples s in [sample_begin, sample_end) of colour() (background
+ * RT_BG_BLACK) or colourUnlit() (RT_BG_SKY) for the camera path (pixel, s), max_depth bounces
+ * (the reference passes 100).  Linear radiance sums; the image does not depend on how the sample
+ * range is split over calls or GPUs except for fp32 summation order.  Asynchronous on the
+ * context's stream. */
+int  rt_render_accumulate(rt_ctx* c, int width, int height, uint32_t sample_begin, uint32_t sample_end,
+                          uint64_t seed, int max_depth, int background, float* accum_dev);
+/* rgb_dev = gamma ? sqrtf(accum/spp) : accum/spp   (main.cu:192-196).  Asynchronous. */
+int  rt_resolve(rt_ctx* c, const float* accum_dev, int width, int height, uint32_t spp, int gamma,
+                float* rgb_dev);
+int  rt_synchronize(rt_ctx* c);
+int  rt_get_counters(rt_ctx* c, rt_counters* out);   /* synchronizes first */
+int  rt_reset_counters(rt_ctx* c);
+
+/* ---- image output (replaces the quantise loop of main(), main.cu:668-697) ---- */
+/* rgb (host, W*H*3, row 0 = bottom) -> 8-bit, rows flipped to top-down, int(255.99*c) clamped to
+ * 0..255 (the reference does not clamp and wraps above 1).  out is W*H*3 bytes. */
+int  rt_quantise_rgb8(const float* rgb, int width, int height, uint8_t* out);
+int  rt_write_ppm(const char* path, const uint8_t* rgb8, int width, int height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

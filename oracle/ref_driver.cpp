@@ -1,0 +1,287 @@
+/*
+ * ref_driver.cpp — TEST INFRASTRUCTURE.  Host build of the REFERENCE's own headers.
+ *
+ * This file is the only translation unit of oracle/_ref/libref.so.  It #includes the
+ * reference's .cuh sources WHERE THEY LIE (-I/root/reference/raytracer; nothing is
+ * copied into this repository) and exposes their hit()/scatter()/value() code through a
+ * small C interface, so that oracle/gen_golden.py can record golden vectors and check
+ * oracle/rt_oracle.c against the real thing.  It only builds where /root/reference exists.
+ *
+ * What is included, and how it compiles with no stand-in headers:
+ *   Vector3 Ray Aabb Hitable HitableList Surface Sphere Triangle Rectangle Box Transform
+ *   Texture Material.  `__host__`/`__device__` come from the image's own <hip/hip_runtime.h>,
+ *   which defines them empty for a non-HIP C++ compile.  Material.cuh names curandState and
+ *   curand_uniform without including anything; they are bound below to the image's real
+ *   rocRAND Philox4x32-10 device engine, which is host-callable — the generator the
+ *   north_star prescribes in place of cuRAND's XORWOW.
+ * What is NOT included: Camera.cuh and Volumes.cuh (#include <curand_kernel.h>, which this
+ *   image does not have), BvhNode.cuh (not the parity target: SURVEY 2, Aabb.cuh:50,53 bug)
+ *   and main.cu (CUDA runtime).  Those parts of the path are restated in rt_oracle.c and
+ *   marked parity-unpinned there.
+ *
+ * Compile with clang++ (left-to-right evaluation of Vector3(xi,xi,xi) arguments, the order
+ * the restatement documents).
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include <hip/hip_runtime.h>
+#include <rocrand/rocrand_philox4x32_10.h>
+#include <rocrand/rocrand_uniform.h>
+
+typedef rocrand_state_philox4x32_10 curandState;
+static inline float curand_uniform(curandState* s) { return rocrand_uniform(s); }
+
+#include "Vector3.cuh"
+#include "Ray.cuh"
+#include "HitableList.cuh"
+#include "Sphere.cuh"
+#include "Triangle.cuh"
+#include "Material.cuh"
+#include "Surface.cuh"
+#include "Rectangle.cuh"
+#include "Box.cuh"
+#include "Transform.cuh"
+
+#include "../include/rt_scene.h"
+#include "rt_oracle.h" /* rto_hit / rto_scatter_out record layouts are shared */
+
+namespace {
+
+/* Triangle has no boundingBox() in the reference and is therefore abstract; this adds the
+ * missing override and nothing else, so Triangle::hit below is the reference's own code. */
+struct TriangleWithBox : public Triangle {
+    TriangleWithBox(Vector3 a, Vector3 b, Vector3 c, Material* m) : Triangle(a, b, c, m) {}
+    bool boundingBox(float, float, Aabb& box) const override
+    {
+        box = Aabb(v0, v0);
+        return true;
+    }
+};
+/* the range filter SURVEY 8(a) A7 adds on top of the unmodified Triangle::hit */
+struct RangedTriangle : public Surface {
+    TriangleWithBox tri;
+    RangedTriangle(Vector3 a, Vector3 b, Vector3 c, Material* m) : tri(a, b, c, m) {}
+    bool hit(const Ray& r, float tMin, float tMax, Intersect& rec) const override
+    {
+        Intersect tmp;
+        if (!tri.hit(r, tMin, tMax, tmp)) return false;
+        if (!(tmp.t < tMax && tmp.t > tMin)) return false;
+        tmp.u = 0.f; tmp.v = 0.f; tmp.bFrontFace = false;
+        rec = tmp;
+        return true;
+    }
+    bool boundingBox(float a, float b, Aabb& box) const override { return tri.boundingBox(a, b, box); }
+};
+
+struct RefScene {
+    const rt_flat_scene* s;
+    std::vector<Texture*> textures;
+    std::vector<Material*> materials;
+    std::vector<Hitable*> objects; /* built lazily per object index, with wrappers */
+    bool id_materials;             /* leaves carry (Material*)(prim_id+1) instead of real ones */
+};
+
+Texture* build_texture(RefScene& R, int ti)
+{
+    if (ti < 0) return nullptr;
+    if (R.textures[ti]) return R.textures[ti];
+    const rt_texture& t = R.s->textures[ti];
+    Texture* out = nullptr;
+    switch (t.type) {
+    case RT_TEX_CONSTANT: out = new ConstantTexture(Vector3(t.colour[0], t.colour[1], t.colour[2])); break;
+    case RT_TEX_CHECKER:  out = new CheckerTexture(build_texture(R, t.even), build_texture(R, t.odd)); break;
+    default:              out = new ImageTexture(const_cast<unsigned char*>(R.s->image_bytes + t.image_offset), t.width, t.height); break;
+    }
+    R.textures[ti] = out;
+    return out;
+}
+
+Material* build_material(RefScene& R, int mi)
+{
+    if (mi < 0) return nullptr;
+    if (R.materials[mi]) return R.materials[mi];
+    const rt_material& m = R.s->materials[mi];
+    Material* out = nullptr;
+    switch (m.type) {
+    case RT_MAT_LAMBERT:   out = new Lambert(build_texture(R, m.texture)); break;
+    case RT_MAT_METAL:     out = new Metal(build_texture(R, m.texture), m.param); break;
+    case RT_MAT_GLASS:     out = new Glass(m.param); break;
+    case RT_MAT_LIGHT:     out = new DiffuseLight(build_texture(R, m.texture)); break;
+    default:               out = new Isotropic(build_texture(R, m.texture)); break;
+    }
+    R.materials[mi] = out;
+    return out;
+}
+
+Hitable* build_object(RefScene& R, int oi)
+{
+    if (R.objects[oi]) return R.objects[oi];
+    const rt_object& o = R.s->objects[oi];
+    const float* f = o.f;
+    Material* mat = R.id_materials ? (Material*)(uintptr_t)(o.prim_id + 1) : build_material(R, o.material);
+    Hitable* h = nullptr;
+    Surface* surf = nullptr;
+    switch (o.type) {
+    case RT_OBJ_SPHERE:        h = surf = new Sphere(Vector3(f[0], f[1], f[2]), f[3], mat); break;
+    case RT_OBJ_MOVING_SPHERE: h = surf = new MovingSphere(Vector3(f[0], f[1], f[2]), Vector3(f[3], f[4], f[5]), f[6], f[7], f[8], mat); break;
+    case RT_OBJ_RECT_XY:       h = surf = new XYRect(f[0], f[1], f[2], f[3], f[4], mat); break;
+    case RT_OBJ_RECT_XZ:       h = surf = new XZRect(f[0], f[1], f[2], f[3], f[4], mat); break;
+    case RT_OBJ_RECT_YZ:       h = surf = new YZRect(f[0], f[1], f[2], f[3], f[4], mat); break;
+    case RT_OBJ_BOX:           h = surf = new Box(Vector3(f[0], f[1], f[2]), Vector3(f[3], f[4], f[5]), mat); break;
+    case RT_OBJ_TRIANGLE:      h = surf = new RangedTriangle(Vector3(f[0], f[1], f[2]), Vector3(f[3], f[4], f[5]), Vector3(f[6], f[7], f[8]), mat); break;
+    case RT_OBJ_GROUP: {
+        /* flat-list semantics are the parity target for groups (SURVEY 7 "Hard parts") */
+        std::vector<Hitable*> kids;
+        for (int i = 0; i < o.child_count; ++i) {
+            Hitable* k = build_object(R, o.child_begin + i);
+            if (k) kids.push_back(k);
+        }
+        Hitable** arr = new Hitable*[kids.size() + 1];
+        for (size_t i = 0; i < kids.size(); ++i) arr[i] = kids[i];
+        h = new HitableList(arr, (int)kids.size());
+    } break;
+    default: /* RT_OBJ_MEDIUM: Volumes.cuh is not buildable here */
+        return nullptr;
+    }
+    if ((o.flags & RT_OBJ_FLAG_FLIP) && surf && o.type >= RT_OBJ_RECT_XY && o.type <= RT_OBJ_RECT_YZ) {
+        /* FlipNormals reads p->matPtr of the Surface base, which the rect ctors leave unset
+         * (they shadow it); it only matters for the pointer it copies, never used in hit() */
+        h = new FlipNormals(surf);
+    }
+    for (int k = o.op_count - 1; k >= 0; --k) {
+        const rt_xform_op& op = R.s->ops[o.op_begin + k];
+        if (op.type == RT_OP_TRANSLATE) h = new Translate(h, Vector3(op.a, op.b, op.c));
+        else {
+            RotateY* r = new RotateY(h, 0.f);
+            r->sinTheta = op.a; /* the flat scene stores sin/cos; ref_rotate_sincos() checks how */
+            r->cosTheta = op.b; /* they are derived from the angle                              */
+            h = r;
+        }
+    }
+    R.objects[oi] = h;
+    return h;
+}
+
+RefScene make(const rt_flat_scene* s, bool ids)
+{
+    RefScene R;
+    R.s = s;
+    R.id_materials = ids;
+    R.textures.assign((size_t)s->n_textures, nullptr);
+    R.materials.assign((size_t)s->n_materials, nullptr);
+    R.objects.assign((size_t)s->n_objects, nullptr);
+    return R;
+}
+
+void record(rto_hit* o, bool h, const Intersect& rec)
+{
+    memset(o, 0, sizeof *o);
+    o->hit = h ? 1 : 0;
+    o->prim = -1;
+    if (!h) return;
+    o->prim = (int32_t)((uintptr_t)rec.matPtr) - 1;
+    o->t = rec.t; o->u = rec.u; o->v = rec.v;
+    for (int k = 0; k < 3; ++k) { o->p[k] = rec.p[k]; o->n[k] = rec.normal[k]; }
+    o->front_face = rec.bFrontFace ? 1 : 0;
+    o->material = -1;
+}
+
+} // namespace
+
+extern "C" {
+
+/* closest hit of `object` (with its wrappers; object = scene->world for the whole list) */
+void ref_object_hit(const rt_flat_scene* s, int object, int n, const float* rays, float tmin, float tmax,
+                    rto_hit* out)
+{
+    RefScene R = make(s, true);
+    Hitable* h = build_object(R, object);
+    for (int i = 0; i < n; ++i) {
+        const float* q = rays + 7 * (size_t)i;
+        Ray r(Vector3(q[0], q[1], q[2]), Vector3(q[3], q[4], q[5]), q[6]);
+        Intersect rec;
+        memset(&rec, 0, sizeof rec);
+        bool hit = h && h->hit(r, tmin, tmax, rec);
+        record(&out[i], hit, rec);
+    }
+}
+
+void ref_texture_value(const rt_flat_scene* s, int texture, int n, const float* uvp, float* rgb)
+{
+    RefScene R = make(s, false);
+    Texture* t = build_texture(R, texture);
+    for (int i = 0; i < n; ++i) {
+        const float* q = uvp + 5 * (size_t)i;
+        Vector3 c = t->value(q[0], q[1], Vector3(q[2], q[3], q[4]));
+        for (int k = 0; k < 3; ++k) rgb[3 * (size_t)i + k] = c[k];
+    }
+}
+
+void ref_uniforms(uint64_t seed, uint32_t pixel, uint32_t sample, int n, float* out)
+{
+    curandState st;
+    rocrand_init(seed, (unsigned long long)pixel | ((unsigned long long)sample << 32), 0ULL, &st);
+    for (int i = 0; i < n; ++i) out[i] = curand_uniform(&st);
+}
+
+void ref_scatter(const rt_flat_scene* s, int material, int n, const float* ray_in, const float* rec_in,
+                 uint64_t seed, const uint32_t* pixel_sample, rto_scatter_out* out)
+{
+    RefScene R = make(s, false);
+    Material* m = build_material(R, material);
+    std::vector<float> stream(4096);
+    for (int i = 0; i < n; ++i) {
+        const float* q = ray_in + 7 * (size_t)i;
+        const float* h = rec_in + 9 * (size_t)i;
+        Ray r(Vector3(q[0], q[1], q[2]), Vector3(q[3], q[4], q[5]), q[6]);
+        Intersect rec;
+        memset(&rec, 0, sizeof rec);
+        rec.t = h[0]; rec.u = h[1]; rec.v = h[2];
+        rec.p = Vector3(h[3], h[4], h[5]);
+        rec.normal = Vector3(h[6], h[7], h[8]);
+        rec.matPtr = m;
+        curandState st;
+        unsigned long long subseq = (unsigned long long)pixel_sample[2 * i] | ((unsigned long long)pixel_sample[2 * i + 1] << 32);
+        rocrand_init(seed, subseq, 0ULL, &st);
+        Vector3 att(0, 0, 0);
+        Ray sc(Vector3(0, 0, 0), Vector3(0, 0, 0), 0.f);
+        Vector3 em = m->emitted(rec.u, rec.v, rec.p);
+        rto_scatter_out* o = &out[i];
+        o->ok = m->scatter(r, rec, att, sc, &st) ? 1 : 0;
+        for (int k = 0; k < 3; ++k) {
+            o->attenuation[k] = att[k];
+            o->origin[k] = sc.origin()[k];
+            o->direction[k] = sc.direction()[k];
+            o->emitted[k] = em[k];
+        }
+        o->time = sc.time();
+        /* how many uniforms did scatter() consume?  locate the next two draws in a fresh stream */
+        ref_uniforms(seed, pixel_sample[2 * i], pixel_sample[2 * i + 1], (int)stream.size(), stream.data());
+        float n0 = curand_uniform(&st), n1 = curand_uniform(&st);
+        o->draws = 0xFFFFFFFFu;
+        for (size_t k = 0; k + 1 < stream.size(); ++k)
+            if (stream[k] == n0 && stream[k + 1] == n1) { o->draws = (uint32_t)k; break; }
+    }
+}
+
+/* how RotateY's constructor turns degrees into sin/cos (Transform.cuh:59-61) */
+void ref_rotate_sincos(float degrees, float* sin_out, float* cos_out)
+{
+    Sphere dummy(Vector3(0, 0, 0), 1.f, nullptr);
+    RotateY r(&dummy, degrees);
+    *sin_out = r.sinTheta;
+    *cos_out = r.cosTheta;
+}
+
+/* Metal's fuzz clamp (Material.cuh:71) as the constructor applies it */
+float ref_metal_fuzz(float f)
+{
+    Metal m(nullptr, f);
+    return m.fuzz;
+}
+
+} // extern "C"
