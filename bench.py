@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the path-tracing hot path on MI355X.
+
+A step = one full render of the workload: every rank renders its own range of `spp` samples per
+pixel of the frame into an fp32 accumulation buffer resident in HBM (C ABI rt_render_accumulate),
+the buffers are summed onto rank 0 (one RCCL reduce; nothing to do at N=1) and rank 0 resolves
+(mean + sqrt gamma).  Per-GPU work is fixed as N grows (weak scaling: N GPUs = N x spp samples).
+
+Default workload = BASELINE.json configs[1]: Cornell box, 1024x1024, 1024 spp, depth 100.
+A ray = one closest-hit query = one iteration of colour()'s loop (reference main.cu:53-56).
+
+  python bench.py [--gpus N --steps K --warmup W] [--workload cornell|cornell_smoke|tri_mesh|final]
+                  [--width --height --spp] [--no-cpu-baseline]
+N>1 is launched by torch.distributed.run (one process per GPU).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+# algorithmic flop weights per unit of work, SURVEY.md 8(d) / DESIGN.md "Roofline"
+F_RECT, F_SPHERE, F_TRI, F_NODE, F_ROT, F_TRANS = 15.0, 30.0, 105.0, 50.0, 12.0, 3.0
+F_SHADE, F_SPHERE_ITER, F_PHILOX = 60.0, 20.0, 100.0
+PEAK_VALU_TFLOPS = 157.3   # MI355X fp32 vector peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0      # HBM3E spec peak
+
+WORKLOADS = {
+    # name: (scene, param, width, height, spp)
+    "cornell": ("cornell", 0, 1024, 1024, 1024),
+    "cornell_smoke": ("cornell_smoke", 0, 1024, 1024, 2048),
+    "tri_mesh": ("tri_mesh", 1000000, 1920, 1080, 256),
+    "final": ("final", 100, 3840, 2160, 4096),
+}
+
+
+def flops_per_ray(st):
+    """algorithmic fp32 ops per ray from the instrumented CPU traversal of the same workload"""
+    rays = max(1, st.rays)
+    f = (F_RECT * st.rect_tests + F_SPHERE * st.sphere_tests + F_TRI * st.tri_tests + F_NODE * st.nodes_visited
+         + F_ROT * st.rot_ops + F_TRANS * st.trans_ops + F_SPHERE_ITER * st.sphere_iters + F_PHILOX * st.philox_blocks) / rays
+    return f + F_SHADE
+
+
+def bytes_per_ray(st, width, height, spp, scene_bytes):
+    """algorithmic HBM bytes per ray of the register-resident integrator: BVH nodes (32 B) and BVH-leaf
+    primitives (128 B rows) fetched per ray, plus the accumulation buffer read+write (24 B/pixel per
+    launch) and one read of the scene tables, amortised over the launch's rays."""
+    rays = max(1, st.rays)
+    per_ray = 32.0 * st.nodes_visited / rays
+    if st.nodes_visited:
+        per_ray += 128.0 * st.prim_tests / rays
+    samples = max(1, st.samples)
+    rays_per_launch = (rays / samples) * width * height * spp
+    return per_ray + (24.0 * width * height + scene_bytes) / rays_per_launch
+
+
+def cpu_baseline(binding, oracle_mod, scene_name, param, background, use_bvh, budget_s=12.0):
+    """the oracle (a scalar port of the reference, see oracle/rt_oracle.c) on the host cores, on a bounded
+    sample of the same workload: the same scene and camera at 128x128, 4 spp per pass, for ~budget_s."""
+    W = H = 128
+    scene = binding.Scene(scene_name, W, H, param)
+    orc = oracle_mod.Oracle()
+    threads = max(1, min(16, os.cpu_count() or 1))
+    import numpy as np
+    acc = np.zeros((H, W, 3), dtype=np.float32)
+    tot = None
+    t0 = time.perf_counter()
+    s = 0
+    while True:
+        _, st = orc.render(scene.flat, W, H, s, s + 4, 419, 100, background, use_bvh=use_bvh, threads=threads, accum=acc)
+        s += 4
+        if tot is None:
+            tot = st
+        else:
+            for name, _ in st._fields_:
+                setattr(tot, name, getattr(tot, name) + getattr(st, name))
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    # one-core rate on a short slice
+    t1 = time.perf_counter()
+    _, st1 = orc.render(scene.flat, W, H, 0, 1, 419, 100, background, use_bvh=use_bvh, threads=1)
+    dt1 = time.perf_counter() - t1
+    return {
+        "value": tot.rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "sample": "%s at %dx%d, %d spp, depth 100, %d threads, %.1f s" % (scene_name, W, H, s, threads, dt),
+        "value_1core": st1.rays / dt1 / 1e6,
+    }, tot
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cornell", choices=sorted(WORKLOADS))
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--spp", type=int, default=0)
+    ap.add_argument("--param", type=int, default=-1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+        sys.exit("bench.py: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no GPU visible")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    b = entry.load_binding()
+    scene_name, param, W, H, spp = WORKLOADS[args.workload]
+    W, H, spp = args.width or W, args.height or H, args.spp or spp
+    if args.param >= 0:
+        param = args.param
+    scene = b.Scene(scene_name, W, H, param)
+    flat = scene.flat.contents
+    background = scene.background
+    has_bvh = flat.n_bvh_nodes > 0
+    scene_bytes = (flat.n_objects * 128 + flat.n_ops * 16 + flat.n_materials * 16 + flat.n_textures * 40
+                   + flat.n_image_bytes + flat.n_bvh_nodes * 32 + flat.n_bvh_items * 4)
+
+    stream = torch.cuda.current_stream(dev)
+    ctx = b.Context(local_rank, stream.cuda_stream)
+    ctx.upload(scene)
+    accum = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
+    rgb = None
+
+    def step(k):
+        nonlocal rgb
+        accum.zero_()
+        s0 = (k * world + rank) * spp            # every step and rank renders fresh sample indices
+        ctx.render_accumulate(accum, W, H, s0, s0 + spp, 419, 100, background)
+        if world > 1:
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            rgb = ctx.resolve(accum, W, H, spp * world, gamma=True)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for k in range(args.warmup):
+        step(k)
+    fence()
+    ctx.reset_counters()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    fence()
+    dt = time.perf_counter() - t0
+    c = ctx.counters()
+
+    tot = torch.tensor([float(c.rays), float(c.samples)], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt, c.render_ms / max(1, c.render_launches)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    rays, samples = tot.tolist()
+    dt, kernel_ms = tmax.tolist()
+
+    if rank == 0:
+        finite = bool(torch.isfinite(rgb).all().item())
+        mean_rgb = float(rgb.mean().item())
+        out = {
+            "metric": "Mrays/s", "value": rays / dt / 1e6, "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s_%dx%d_%dspp" % (args.workload, W, H, spp), "scene": scene_name,
+                       "width": W, "height": H, "spp_per_gpu": spp, "max_depth": 100,
+                       "background": "sky" if background else "black", "bvh": has_bvh,
+                       "parallelism": "spp-shard x%d + RCCL reduce" % world if world > 1 else "single GPU"},
+            "samples_per_s": samples / dt, "rays_per_sample": rays / max(1.0, samples),
+            "image_mean": mean_rgb, "image_finite": finite,
+        }
+        base_stats = None
+        if not args.no_cpu_baseline and world == 1:
+            o = entry.load_oracle()
+            out["cpu_baseline"], base_stats = cpu_baseline(b, o, scene_name, param, background, has_bvh)
+        elif world == 1:
+            out["cpu_baseline"] = None
+        # roofline of the dominant kernel (render_kernel), duration from HIP events on its own stream
+        rays_per_launch = rays / world / max(1, c.render_launches)
+        roof = {"bound": "valu", "kernel": "render_kernel", "kernel_ms": kernel_ms, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
+                "achieved": None, "frac": None, "traffic": None,
+                "hbm_peak_GBs": PEAK_HBM_GBS, "hbm_achieved_GBs": None, "hbm_frac": None}
+        if base_stats is not None and kernel_ms > 0:
+            fpr = flops_per_ray(base_stats)
+            bpr = bytes_per_ray(base_stats, W, H, spp, scene_bytes)
+            ach = rays_per_launch * fpr / (kernel_ms * 1e-3) / 1e12
+            hb = rays_per_launch * bpr / (kernel_ms * 1e-3) / 1e9
+            roof.update({"achieved": ach, "frac": ach / PEAK_VALU_TFLOPS, "flops_per_ray": fpr, "bytes_per_ray": bpr,
+                         "hbm_achieved_GBs": hb, "hbm_frac": hb / PEAK_HBM_GBS})
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                roof["traffic"] = json.load(open(tpath)).get(out["config"]["workload"])
+            except Exception:
+                pass
+        out["roofline"] = roof
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -279,6 +279,16 @@ struct Lowerer {
         } else out.push_back(h);
     }
 
+    static bool is_surface(Hitable* h)
+    {
+        while (h && (h->kind() == Hitable::TRANSLATE || h->kind() == Hitable::ROTATE_Y || h->kind() == Hitable::FLIP)) {
+            if (h->kind() == Hitable::TRANSLATE) h = static_cast<Translate*>(h)->hitablePtr;
+            else if (h->kind() == Hitable::ROTATE_Y) h = static_cast<RotateY*>(h)->hitablePtr;
+            else h = static_cast<FlipNormals*>(h)->surfacePtr;
+        }
+        return h && h->kind() != Hitable::LIST && h->kind() != Hitable::BVH && h->kind() != Hitable::MEDIUM;
+    }
+
     void set_bounds(rt_object& o, Box3 b)
     {
         for (int i = o.op_count - 1; i >= 0; --i) b = apply_op(b, S.ops[o.op_begin + i]);
@@ -375,6 +385,19 @@ struct Lowerer {
             std::vector<Hitable*> members;
             if (h->kind() == Hitable::LIST) gather(h, members);
             else for (Hitable* m : static_cast<BvhNode*>(h)->members) gather(m, members);
+            /* A long world list that also holds groups or media would be scanned linearly.  Closest hit
+             * does not depend on list order (except exact ties), so its plain surfaces are moved into one
+             * synthetic BVH group placed first; groups and media keep their relative order after it. */
+            BvhNode surfaces;
+            if (depth == 0) {
+                std::vector<Hitable*> rest;
+                for (Hitable* m : members) (is_surface(m) ? surfaces.members : rest).push_back(m);
+                if (!rest.empty() && (int)surfaces.members.size() >= opt.bvh_min_children) {
+                    members.clear();
+                    members.push_back(&surfaces);
+                    members.insert(members.end(), rest.begin(), rest.end());
+                }
+            }
             o.child_begin = (int)S.objects.size();
             o.child_count = (int)members.size();
             S.objects.resize(S.objects.size() + members.size());

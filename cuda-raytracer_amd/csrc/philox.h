@@ -2,16 +2,18 @@
  * philox.h — Philox4x32-10 counter-based RNG (Salmon et al., SC'11), the
  * replacement for the per-pixel XORWOW curandState of reference main.cu:108-117.
  *
- * Stream definition (identical in the oracle and in the kernels):
+ * Stream definition (identical in the oracle and in the kernels).  Every consumer of randomness
+ * owns whole blocks addressed by what they are for, so no draw depends on how many draws another
+ * consumer made (no serial stream to keep in step across divergent lanes):
  *   key     = (seed_lo, seed_hi)
- *   counter = (block, lane_stream, pixel, sample)
- * A path (pixel, sample) draws its uniforms sequentially; draw k is word k&3 of
- * block k>>2 with lane_stream = 0.  Constant-medium free-flight draws use
- * lane_stream = 1 + medium_slot and block = bounce, word 0, so that they do not
- * depend on the order in which media are visited.
- * This is bit-compatible with rocRAND's device engine initialised as
- * rocrand_init(seed, subsequence = pixel | sample<<32, offset = 4*block [+ stream<<34]).
- * Uniforms are in (0,1] like curand_uniform (needed by log(xi), Volumes.cuh:40).
+ *   counter = (c0, purpose<<24 | bounce, pixel, sample)
+ *   RT_RNG_CAMERA  c0=0     words 0,1 = pixel jitter u,v, word 2 = shutter time
+ *   RT_RNG_DISK    c0=iter  words 0,1 = one lens-disk rejection candidate
+ *   RT_RNG_SPHERE  c0=iter  words 0,1,2 = one unit-ball rejection candidate (x first)
+ *   RT_RNG_GLASS   c0=0     word 0 = reflect-or-refract draw
+ *   RT_RNG_MEDIUM  c0=slot  word 0 = free-flight draw of constant medium `slot`
+ * Each block equals rocRAND's device engine at rocrand_init(seed, subsequence = pixel | sample<<32,
+ * offset = 4*(c0 | c1<<32)).  Uniforms are in (0,1] like curand_uniform (log(xi), Volumes.cuh:40).
  */
 #ifndef RT_PHILOX_H
 #define RT_PHILOX_H
@@ -22,6 +24,8 @@
 #else
 #define RT_HD inline
 #endif
+
+enum { RT_RNG_CAMERA = 0, RT_RNG_DISK = 1, RT_RNG_SPHERE = 2, RT_RNG_GLASS = 3, RT_RNG_MEDIUM = 4 };
 
 struct rt_u32x4 { uint32_t x, y, z, w; };
 

@@ -74,29 +74,20 @@ struct HitRec {
 
 /* ------------------------------------------------------------------ RNG ---- */
 struct PathRng {
-    uint32_t k0, k1, pixel, sample, idx;
-    uint32_t b0, b1, b2, b3;
+    uint32_t k0, k1, pixel, sample;
 };
 __device__ __forceinline__ void rng_start(PathRng& g, uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample)
 {
-    g.k0 = k0; g.k1 = k1; g.pixel = pixel; g.sample = sample; g.idx = 0;
-    g.b0 = g.b1 = g.b2 = g.b3 = 0;
+    g.k0 = k0; g.k1 = k1; g.pixel = pixel; g.sample = sample;
 }
-__device__ __forceinline__ float rng_next(PathRng& g)
+/* the block owned by (purpose, c0) at `bounce` of this path — see philox.h */
+__device__ __forceinline__ rt_u32x4 rng_block(const PathRng& g, uint32_t purpose, uint32_t bounce, uint32_t c0)
 {
-    uint32_t w = g.idx & 3u;
-    if (w == 0) {
-        rt_u32x4 r = rt_philox4x32_10(g.idx >> 2, 0u, g.pixel, g.sample, g.k0, g.k1);
-        g.b0 = r.x; g.b1 = r.y; g.b2 = r.z; g.b3 = r.w;
-    }
-    g.idx++;
-    uint32_t v = w == 0 ? g.b0 : (w == 1 ? g.b1 : (w == 2 ? g.b2 : g.b3));
-    return rt_u32_to_uniform(v);
+    return rt_philox4x32_10(c0, (purpose << 24) | bounce, g.pixel, g.sample, g.k0, g.k1);
 }
 __device__ __forceinline__ float rng_medium(const PathRng& g, uint32_t bounce, int slot)
 {
-    rt_u32x4 r = rt_philox4x32_10(bounce, 1u + (uint32_t)slot, g.pixel, g.sample, g.k0, g.k1);
-    return rt_u32_to_uniform(r.x);
+    return rt_u32_to_uniform(rng_block(g, RT_RNG_MEDIUM, bounce, (uint32_t)slot).x);
 }
 
 /* ----------------------------------------------------------- primitives ---- */
@@ -484,12 +475,13 @@ __device__ __forceinline__ V3 texture_value(const DScene& S, int ti, float u, fl
 }
 
 /* --------------------------------------------------------------- materials ---- */
-__device__ __forceinline__ V3 random_in_unit_sphere(PathRng& g)                    /* Material.cuh:34-40 */
+__device__ __forceinline__ V3 random_in_unit_sphere(const PathRng& g, uint32_t bounce)   /* Material.cuh:34-40 */
 {
     V3 p;
+    uint32_t k = 0;
     do {
-        float a = rng_next(g), b = rng_next(g), c = rng_next(g);
-        p = 2.f * mk(a, b, c) - mk(1.f, 1.f, 1.f);
+        rt_u32x4 w = rng_block(g, RT_RNG_SPHERE, bounce, k++);
+        p = 2.f * mk(rt_u32_to_uniform(w.x), rt_u32_to_uniform(w.y), rt_u32_to_uniform(w.z)) - mk(1.f, 1.f, 1.f);
     } while (dot(p, p) >= 1.f);
     return p;
 }
@@ -513,8 +505,8 @@ __device__ __forceinline__ bool refract(V3 v, V3 n, float niOverNt, V3& refracte
 }
 
 /* Material::scatter + emitted (Material.cuh:51-144). Returns false when the path ends. */
-__device__ __forceinline__ bool scatter(const DScene& S, const DRay& in, const HitRec& rec, PathRng& g,
-                                        V3& attenuation, DRay& out, V3& emitted)
+__device__ __forceinline__ bool scatter(const DScene& S, const DRay& in, const HitRec& rec, const PathRng& g,
+                                        uint32_t bounce, V3& attenuation, DRay& out, V3& emitted)
 {
     const rt_material m = S.mats[rec.material];
     emitted = mk(0.f, 0.f, 0.f);
@@ -523,14 +515,14 @@ __device__ __forceinline__ bool scatter(const DScene& S, const DRay& in, const H
     out.time = in.time;
     switch (m.type) {
     case RT_MAT_LAMBERT: {
-        V3 target = rec.p + rec.n + random_in_unit_sphere(g);
+        V3 target = rec.p + rec.n + random_in_unit_sphere(g, bounce);
         out.d = target - rec.p;
         attenuation = texture_value(S, m.texture, rec.u, rec.v, rec.p);
         return true;
     }
     case RT_MAT_METAL: {
         V3 reflected = reflect(unit(in.d), rec.n);
-        out.d = reflected + m.param * random_in_unit_sphere(g);
+        out.d = reflected + m.param * random_in_unit_sphere(g, bounce);
         attenuation = texture_value(S, m.texture, 0, 0, rec.p);
         return dot(out.d, rec.n) > 0.f;
     }
@@ -553,14 +545,14 @@ __device__ __forceinline__ bool scatter(const DScene& S, const DRay& in, const H
         }
         if (refract(in.d, outwardNorm, niOverNt, refracted)) reflectProb = schlick(cosine, refIdx);
         else reflectProb = 1.f;
-        out.d = rng_next(g) < reflectProb ? reflected : refracted;
+        out.d = rt_u32_to_uniform(rng_block(g, RT_RNG_GLASS, bounce, 0u).x) < reflectProb ? reflected : refracted;
         return true;
     }
     case RT_MAT_LIGHT:
         emitted = texture_value(S, m.texture, rec.u, rec.v, rec.p);
         return false;
     default: /* Isotropic: time resets to 0 (Material.cuh:140) */
-        out.d = random_in_unit_sphere(g);
+        out.d = random_in_unit_sphere(g, bounce);
         out.time = 0.f;
         attenuation = texture_value(S, m.texture, rec.u, rec.v, rec.p);
         return true;
@@ -568,16 +560,21 @@ __device__ __forceinline__ bool scatter(const DScene& S, const DRay& in, const H
 }
 
 /* ------------------------------------------------------------------ camera ---- */
-__device__ __forceinline__ DRay generate_ray(const rt_camera& c, float s, float t, PathRng& g)   /* Camera.cuh:40-46 */
+__device__ __forceinline__ DRay generate_ray(const rt_camera& c, float s, float t, float xi_time, const PathRng& g)   /* Camera.cuh:40-46 */
 {
-    V3 p;
-    do {                                                                             /* randomInUnitDisk :12-18 */
-        float a = rng_next(g), b = rng_next(g);
-        p = 2.0f * mk(a, b, 0.f) - mk(1.f, 1.f, 0.f);
-    } while (dot(p, p) > 1.f);
+    /* randomInUnitDisk (Camera.cuh:12-18).  Its result is multiplied by lensRadius, and its draws are
+     * addressed blocks of their own, so a pinhole camera skips the loop without changing any other draw. */
+    V3 p = mk(0.f, 0.f, 0.f);
+    if (c.lens_radius != 0.f) {
+        uint32_t k = 0;
+        do {
+            rt_u32x4 w = rng_block(g, RT_RNG_DISK, 0u, k++);
+            p = 2.0f * mk(rt_u32_to_uniform(w.x), rt_u32_to_uniform(w.y), 0.f) - mk(1.f, 1.f, 0.f);
+        } while (dot(p, p) > 1.f);
+    }
     V3 rd = c.lens_radius * p;
     V3 offset = rd.x * ld3(c.u) + rd.y * ld3(c.v);
-    float time = c.time0 + rng_next(g) * (c.time1 - c.time0);
+    float time = c.time0 + xi_time * (c.time1 - c.time0);
     DRay r;
     r.o = ld3(c.origin) + offset;
     r.d = ld3(c.lower_left) + s * ld3(c.horizontal) + t * ld3(c.vertical) - ld3(c.origin) - offset;

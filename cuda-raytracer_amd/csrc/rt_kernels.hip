@@ -112,9 +112,10 @@ __global__ __launch_bounds__(RT_BLOCK) void render_kernel(DScene S, int W, int H
         if (!alive && s < s_end) {
             /* main.cu:185-188: jittered pixel position, camera ray, fresh path */
             rng_start(g, k0, k1, pixel, s);
-            float u = float(i + rng_next(g)) / float(W);
-            float v = float(j + rng_next(g)) / float(H);
-            ray = generate_ray(S.cam, u, v, g);
+            rt_u32x4 cw = rng_block(g, RT_RNG_CAMERA, 0u, 0u);
+            float u = float(i + rt_u32_to_uniform(cw.x)) / float(W);
+            float v = float(j + rt_u32_to_uniform(cw.y)) / float(H);
+            ray = generate_ray(S.cam, u, v, rt_u32_to_uniform(cw.z), g);
             att = mk(1.f, 1.f, 1.f);
             emi = mk(0.f, 0.f, 0.f);
             depth = 0;
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(RT_BLOCK) void render_kernel(DScene S, int W, int H
                 rebuild(S, ray, hl, .001f, rec);
                 V3 attenuation, emitted;
                 DRay scattered;
-                if (scatter(S, ray, rec, g, attenuation, scattered, emitted)) {
+                if (scatter(S, ray, rec, g, (uint32_t)depth, attenuation, scattered, emitted)) {
                     att = att * attenuation;
                     if (BG == RT_BG_BLACK) emi = emi + emitted * att;
                     ray = scattered;

@@ -312,6 +312,9 @@ Built kat(int width, int height)
     list[i++] = new RotateY(new Translate(new Sphere(Vector3(0, 0, 0), .6f, met), Vector3(4, 1.5f, 0)), -50);
     list[i++] = new Triangle(Vector3(-1, 2, -2), Vector3(1, 2.2f, -2.5f), Vector3(0, 3.5f, -1.5f), lam);
     list[i++] = new Translate(new Triangle(Vector3(0, 0, 0), Vector3(2, 0, .5f), Vector3(.5f, 1.5f, 0), met), Vector3(-5, 2, 3));
+    curandState unused;
+    curand_init(419, 0, 0, &unused);
+    list[i++] = new ConstantMedium(new Sphere(Vector3(-1.5f, 1.f, 4.f), 1.2f, gls), .8f, new ConstantTexture(Vector3(.9, .5, .3)), &unused);
     Built b;
     b.world = new HitableList(list, i);
     b.cam = look(Vector3(2, 3, -12), Vector3(0, .5f, 0), 45.f, width, height, 0.05f, 12.f);

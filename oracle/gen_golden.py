@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""gen_golden.py — TEST INFRASTRUCTURE.  Writes the fixtures under tests/golden/.
+
+Run in the container that has /root/reference (after `make -C oracle` has produced
+oracle/_ref/libref.so).  Every expected value in the *_ref.npz files comes out of the REFERENCE's
+own hit()/scatter()/value() code, host-compiled by oracle/ref_driver.cpp; inputs are seeded numpy
+draws.  The converged images (images_*.npz) come from the CPU restatement oracle/rt_oracle.c,
+because the reference's integrator (main.cu) cannot be built here.
+
+Each fixture stores a digest of the scene tables it was made from; tests refuse a stale fixture.
+  python oracle/gen_golden.py [--images]       (--images adds the slow converged renders)
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+FLT_MAX = float(np.finfo(np.float32).max)
+
+
+def rays_at_box(rng, bmin, bmax, n, time_lo=0.0, time_hi=1.0):
+    """rays from around the box towards points in (a slightly inflated copy of) it, un-normalised"""
+    bmin, bmax = np.asarray(bmin, np.float64), np.asarray(bmax, np.float64)
+    ext = np.maximum(bmax - bmin, 1e-3)
+    ctr = 0.5 * (bmin + bmax)
+    rad = 0.5 * np.linalg.norm(ext)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    org = ctr + d * rad * rng.uniform(0.2, 4.0, size=(n, 1))     # some origins are inside
+    tgt = ctr + (rng.random((n, 3)) - 0.5) * ext * 1.3
+    dirs = (tgt - org) * rng.uniform(0.3, 3.0, size=(n, 1))
+    t = rng.uniform(time_lo, time_hi, size=(n, 1))
+    return np.concatenate([org, dirs, t], axis=1).astype(np.float32)
+
+
+def camera_rays(rng, cam, n):
+    org = np.array(cam.origin[:], np.float32)
+    st = rng.random((n, 2)).astype(np.float32)
+    d = (np.array(cam.lower_left[:], np.float32) + st[:, :1] * np.array(cam.horizontal[:], np.float32)
+         + st[:, 1:] * np.array(cam.vertical[:], np.float32) - org)
+    return np.concatenate([np.tile(org, (n, 1)), d, rng.random((n, 1)).astype(np.float32)], axis=1).astype(np.float32)
+
+
+GEOM_SCENES = [("kat", 0), ("cornell", 0), ("lit_sphere", 0), ("bvh_boxes", 0), ("random_spheres", 0),
+               ("cornell_cluster", 0), ("final", 6), ("tri_mesh", 800)]
+W, H = 128, 72
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--images", action="store_true")
+    args = ap.parse_args()
+    b = entry.load_binding()
+    o = entry.load_oracle()
+    global scene_digest
+    scene_digest = o.scene_digest
+    ref, orc = o.Reference(), o.Oracle()
+    os.makedirs(GOLD, exist_ok=True)
+    rng = np.random.default_rng(20261110)
+
+    # ---- 1. per-object and whole-world closest hits -------------------------------------------
+    for name, param in GEOM_SCENES:
+        sc = b.Scene(name, W, H, param)
+        f = sc.flat.contents
+        world = f.objects[f.world]
+        out = {"digest": scene_digest(sc.flat), "param": param, "width": W, "height": H}
+        # individual top-level objects (at most 16 of them), wrappers included
+        kids = [world.child_begin + i for i in range(world.child_count)]
+        picks = kids if len(kids) <= 16 else [kids[i] for i in sorted(rng.choice(len(kids), 16, replace=False))]
+        obj_ix, obj_rays, obj_hits = [], [], []
+        for oi in picks:
+            ob = f.objects[oi]
+            if ob.type == 7:      # media are not buildable from the reference here
+                continue
+            r = rays_at_box(rng, ob.bmin[:], ob.bmax[:], 384)
+            hits = ref.object_hit(sc.flat, oi, r, 0.001, FLT_MAX)
+            obj_ix.append(oi); obj_rays.append(r); obj_hits.append(hits)
+        out["obj_index"] = np.array(obj_ix, np.int32)
+        out["obj_rays"] = np.stack(obj_rays)
+        out["obj_hits"] = np.stack(obj_hits)
+        # a bounded (tmin,tmax) window on the same rays of the first object
+        out["win_rays"] = obj_rays[0]
+        tm = np.median(obj_hits[0]["t"][obj_hits[0]["hit"] == 1]) if (obj_hits[0]["hit"] == 1).any() else 1.0
+        out["win_range"] = np.array([0.25 * tm, 1.0 * tm], np.float32)
+        out["win_hits"] = ref.object_hit(sc.flat, picks[0], obj_rays[0], float(out["win_range"][0]), float(out["win_range"][1]))
+        # whole world: camera rays + bounce-like rays leaving hit points
+        cr = camera_rays(rng, f.camera, 3000)
+        h0 = ref.object_hit(sc.flat, f.world, cr, 0.001, FLT_MAX)
+        br = cr.copy()
+        m = h0["hit"] == 1
+        br[m, 0:3] = h0["p"][m]
+        br[:, 3:6] = rng.normal(size=(len(br), 3)).astype(np.float32)
+        wr = np.concatenate([cr, br]).astype(np.float32)
+        out["world_rays"] = wr
+        out["world_hits"] = ref.object_hit(sc.flat, f.world, wr, 0.001, FLT_MAX)
+        # primary-hit map (pinhole-centre rays, the same ones rt_trace_primary builds)
+        po, to = orc.trace_primary(sc.flat, W, H)           # restatement, to recover the rays' results
+        cam = f.camera
+        jj, ii = np.mgrid[0:H, 0:W]
+        u = ((ii + np.float32(0.5)).astype(np.float32) / np.float32(W)).astype(np.float32)
+        v = ((jj + np.float32(0.5)).astype(np.float32) / np.float32(H)).astype(np.float32)
+        ll, hz, vt, og = (np.array(x[:], np.float32) for x in (cam.lower_left, cam.horizontal, cam.vertical, cam.origin))
+        d = ((ll + u[..., None] * hz).astype(np.float32) + v[..., None] * vt).astype(np.float32) - og
+        pr = np.concatenate([np.broadcast_to(og, d.shape), d.astype(np.float32), np.full(d.shape[:2] + (1,), cam.time0, np.float32)], axis=2)
+        ph = ref.object_hit(sc.flat, f.world, pr.reshape(-1, 7), 0.001, FLT_MAX)
+        out["primary_prim"] = ph["prim"].reshape(H, W)
+        out["primary_t"] = np.where(ph["hit"] == 1, ph["t"], 0).astype(np.float32).reshape(H, W)
+        agree = np.array_equal(out["primary_prim"], po) and np.array_equal(out["primary_t"], to)
+        print("%-16s objects %4d  world hits %5d  primary map restatement==reference: %s" % (name, len(obj_ix), int(m.sum()), agree))
+        np.savez_compressed(os.path.join(GOLD, "geom_%s_ref.npz" % name), **out)
+
+    # ---- 2. materials and textures (scene "kat" carries one of each, "random_spheres" the glass) ----
+    sc = b.Scene("kat", W, H)
+    f = sc.flat.contents
+    out = {"digest": scene_digest(sc.flat)}
+    n, XI = 512, 96
+    mats, rays_in, recs, ps, res = [], [], [], [], []
+    for mi in range(f.n_materials):
+        d = rng.normal(size=(n, 3)) * rng.uniform(0.2, 5.0, size=(n, 1))
+        nrm = rng.normal(size=(n, 3))
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        # half the normals face the ray (the usual case), half do not (inside glass)
+        flip = (np.einsum("ij,ij->i", d, nrm) > 0) & (rng.random(n) < 0.5)
+        nrm[flip] *= -1
+        p = rng.uniform(-6, 6, size=(n, 3))
+        ray = np.concatenate([p - d, d, rng.random((n, 1))], axis=1).astype(np.float32)
+        rec = np.concatenate([np.ones((n, 1)), rng.random((n, 2)), p, nrm], axis=1).astype(np.float32)
+        pxs = np.stack([rng.integers(0, 1 << 20, n), rng.integers(0, 4096, n)], axis=1).astype(np.uint32)
+        mats.append(mi); rays_in.append(ray); recs.append(rec); ps.append(pxs)
+        r_out = ref.scatter(sc.flat, mi, ray, rec, 419, pxs)
+        res.append(r_out)
+        # The uniforms the reference's scatter() drew are the first `draws` values of the rocRAND Philox
+        # stream (seed 419, subsequence pixel | sample<<32).  Tests rebuild that stream (misc_ref.npz pins
+        # it) and feed it to the restatement as a script of XI values.
+        assert r_out["draws"].max() < XI - 2, "rejection loop ran past the script length"
+    out.update(mat_index=np.array(mats, np.int32), mat_rays=np.stack(rays_in), mat_recs=np.stack(recs),
+               mat_pixel_sample=np.stack(ps), mat_out=np.stack(res), seed=419, xi_len=XI)
+    texs, uvps, rgbs = [], [], []
+    for ti in range(f.n_textures):
+        uvp = np.concatenate([rng.uniform(-0.1, 1.1, size=(n, 2)), rng.uniform(-6, 6, size=(n, 3))], axis=1).astype(np.float32)
+        uvp[:8, 0] = [0, 1, 0.5, 1, 0, 0.999999, 1e-7, 0.25]      # image clamp edges
+        uvp[:8, 1] = [0, 1, 1, 0, 0.5, 1e-7, 0.999999, 0.75]
+        texs.append(ti); uvps.append(uvp); rgbs.append(ref.texture_value(sc.flat, ti, uvp))
+    out.update(tex_index=np.array(texs, np.int32), tex_uvp=np.stack(uvps), tex_rgb=np.stack(rgbs))
+    np.savez_compressed(os.path.join(GOLD, "shade_kat_ref.npz"), **out)
+    print("materials %d, textures %d" % (len(mats), len(texs)))
+
+    # ---- 3. RNG stream, RotateY constructor, Metal fuzz clamp -----------------------------------
+    keys = [(419, 0, 0), (419, 12345, 7), (0xDEADBEEFCAFE, 1048575, 4095), (1, 1, 1)]
+    uni = np.stack([ref.uniforms(s, p, q, 64) for s, p, q in keys])
+    angles = np.array([-18, 15, 0, 120, 33, -50, 90, 180, 359.5, -0.25], np.float32)
+    sc_ = np.array([ref.rotate_sincos(float(a)) for a in angles], np.float32)
+    fz = np.array([0.0, 0.3, 0.999, 1.0, 1.5, 10.0], np.float32)
+    np.savez_compressed(os.path.join(GOLD, "misc_ref.npz"), rng_keys=np.array(keys, np.uint64), rng_uniforms=uni,
+                        angles=angles, sincos=sc_, fuzz_in=fz, fuzz_out=np.array([ref.metal_fuzz(float(x)) for x in fz], np.float32))
+    print("misc ok")
+
+    # ---- 4. converged images from the restatement (slow) ------------------------------------------
+    if args.images:
+        IW = IH = 48
+        for name, spp, bvh in [("cornell", 262144, False), ("cornell_smoke", 262144, False),
+                               ("random_spheres", 16384, True), ("lit_sphere", 65536, False)]:
+            sc = b.Scene(name, IW, IH)
+            acc, st = orc.render(sc.flat, IW, IH, 0, spp, 1000003, 100, sc.background, use_bvh=bvh, threads=os.cpu_count() or 1)
+            img = (acc / np.float32(spp)).astype(np.float32)
+            np.savez_compressed(os.path.join(GOLD, "image_%s_oracle.npz" % name), digest=scene_digest(sc.flat), image=img,
+                                spp=spp, seed=1000003, width=IW, height=IH, rays=st.rays)
+            print("image %-16s %d spp, %d rays, mean %.5f" % (name, spp, st.rays, img.mean()))
+
+
+if __name__ == "__main__":
+    main()

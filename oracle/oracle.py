@@ -2,6 +2,7 @@
 the reference's own headers (_ref/libref.so).  TEST INFRASTRUCTURE: imported only by tests/,
 __graft_entry__.smoke() and bench.py's cpu_baseline leg."""
 import ctypes as C
+import hashlib
 import os
 
 import numpy as np
@@ -18,7 +19,9 @@ SCATTER_DTYPE = np.dtype([("ok", "<i4"), ("attenuation", "<f4", (3,)), ("origin"
 
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("prim_tests", C.c_uint64),
-                ("nodes_visited", C.c_uint64), ("philox_blocks", C.c_uint64), ("sphere_iters", C.c_uint64)]
+                ("nodes_visited", C.c_uint64), ("philox_blocks", C.c_uint64), ("sphere_iters", C.c_uint64),
+                ("rect_tests", C.c_uint64), ("sphere_tests", C.c_uint64), ("tri_tests", C.c_uint64),
+                ("rot_ops", C.c_uint64), ("trans_ops", C.c_uint64)]
 
 
 def _f32(a):
@@ -56,16 +59,6 @@ class _Common:
         fn(C.cast(flat, C.c_void_p), tex, uvp.shape[0], _ptr(uvp), _ptr(out))
         return out
 
-    def scatter(self, flat, mat, ray_in, rec_in, seed, pixel_sample):
-        ray_in, rec_in = _f32(ray_in), _f32(rec_in)
-        ps = np.ascontiguousarray(pixel_sample, dtype=np.uint32)
-        out = np.zeros(ray_in.shape[0], dtype=SCATTER_DTYPE)
-        fn = self._fn("scatter")
-        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
-        fn.restype = None
-        fn(C.cast(flat, C.c_void_p), mat, ray_in.shape[0], _ptr(ray_in), _ptr(rec_in), seed, _ptr(ps), _ptr(out))
-        return out
-
     def uniforms(self, seed, pixel, sample, n):
         out = np.zeros(n, dtype=np.float32)
         fn = self._fn("uniforms")
@@ -80,6 +73,16 @@ class Oracle(_Common):
         if not os.path.exists(path):
             raise RuntimeError("%s missing: run `make -C oracle`" % path)
         super().__init__(C.CDLL(path), "rto_")
+
+    def scatter(self, flat, mat, ray_in, rec_in, xi):
+        """xi[n, stride]: scripted uniforms, consumed per call in the order the reference draws them"""
+        ray_in, rec_in, xi = _f32(ray_in), _f32(rec_in), _f32(xi)
+        out = np.zeros(ray_in.shape[0], dtype=SCATTER_DTYPE)
+        fn = self.lib.rto_scatter
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        fn.restype = None
+        fn(C.cast(flat, C.c_void_p), mat, ray_in.shape[0], _ptr(ray_in), _ptr(rec_in), _ptr(xi), xi.shape[1], _ptr(out))
+        return out
 
     def trace_rays(self, flat, rays, tmin, tmax, use_bvh=False, stats=None):
         rays = _f32(rays)
@@ -150,6 +153,16 @@ class Reference(_Common):
             raise RuntimeError("%s missing (needs /root/reference): run `make -C oracle`" % path)
         super().__init__(C.CDLL(path), "ref_")
 
+    def scatter(self, flat, mat, ray_in, rec_in, seed, pixel_sample):
+        ray_in, rec_in = _f32(ray_in), _f32(rec_in)
+        ps = np.ascontiguousarray(pixel_sample, dtype=np.uint32)
+        out = np.zeros(ray_in.shape[0], dtype=SCATTER_DTYPE)
+        fn = self._fn("scatter")
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        fn.restype = None
+        fn(C.cast(flat, C.c_void_p), mat, ray_in.shape[0], _ptr(ray_in), _ptr(rec_in), seed, _ptr(ps), _ptr(out))
+        return out
+
     def rotate_sincos(self, degrees):
         s, c = C.c_float(), C.c_float()
         fn = self.lib.ref_rotate_sincos
@@ -163,6 +176,18 @@ class Reference(_Common):
         fn.argtypes = [C.c_float]
         fn.restype = C.c_float
         return fn(f)
+
+
+def scene_digest(flat):
+    """sha1 over the raw bytes of every table of an rt_flat_scene"""
+    f = flat.contents
+    h = hashlib.sha1()
+    for ptr, n, size in [(f.objects, f.n_objects, 104), (f.ops, f.n_ops, 16), (f.materials, f.n_materials, 16),
+                         (f.textures, f.n_textures, 40), (f.image_bytes, f.n_image_bytes, 1)]:
+        if n:
+            h.update(C.string_at(C.cast(ptr, C.c_void_p), int(n) * size))
+    h.update(bytes(f.camera))
+    return h.hexdigest()
 
 
 def reference_available():

@@ -95,35 +95,48 @@ static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t
 }
 static float u32_to_uniform(uint32_t v) { return 2.3283064e-10f + ((float)v * 2.3283064e-10f); } /* (0,1] */
 
+/* Stream layout (same as cuda-raytracer_amd/csrc/philox.h): every consumer of randomness owns whole
+ * Philox blocks addressed by what they are for, so no draw depends on how many draws another
+ * consumer made:  counter = (c0, purpose<<24 | bounce, pixel, sample), key = seed.
+ *   RNG_CAMERA  c0=0        words 0,1 = pixel jitter u,v (main.cu:185-186), word 2 = shutter time (Camera.cuh:44)
+ *   RNG_DISK    c0=iter     words 0,1 = one randomInUnitDisk candidate (Camera.cuh:15)
+ *   RNG_SPHERE  c0=iter     words 0,1,2 = one randomInUnitSphere candidate, x first (Material.cuh:37)
+ *   RNG_GLASS   c0=0        word 0 = the reflect/refract draw (Material.cuh:114)
+ *   RNG_MEDIUM  c0=slot     word 0 = the free-flight draw (Volumes.cuh:40)
+ * For known-answer tests against the reference's own scatter() the draws can instead be scripted:
+ * then every uniform is taken, in the order the reference code asks for them, from a list. */
+enum { RNG_CAMERA = 0, RNG_DISK = 1, RNG_SPHERE = 2, RNG_GLASS = 3, RNG_MEDIUM = 4 };
 typedef struct {
     uint32_t key[2];
     uint32_t pixel, sample;
-    uint32_t idx;      /* sequential draw counter of the path */
-    uint32_t blk[4];
-    uint32_t bounce;   /* keys the medium streams */
+    uint32_t bounce;
+    const float* script;   /* non-NULL: scripted uniforms */
+    uint32_t script_pos;
     rto_stats* st;
 } Rng;
 
 static void rng_init(Rng* g, uint64_t seed, uint32_t pixel, uint32_t sample, rto_stats* st)
 {
     g->key[0] = (uint32_t)seed; g->key[1] = (uint32_t)(seed >> 32);
-    g->pixel = pixel; g->sample = sample; g->idx = 0; g->bounce = 0; g->st = st;
+    g->pixel = pixel; g->sample = sample; g->bounce = 0; g->script = NULL; g->script_pos = 0; g->st = st;
 }
-static float rng_next(Rng* g)                       /* stands for curand_uniform(localRandState) */
+/* n (<=4) uniforms for (purpose, c0) at the current bounce */
+static void rng_draw(Rng* g, int purpose, uint32_t c0, int n, float* out)
 {
-    if ((g->idx & 3u) == 0) {
-        uint32_t c[4] = {g->idx >> 2, 0u, g->pixel, g->sample};
-        philox4x32_10(c, g->key, g->blk);
-        if (g->st) g->st->philox_blocks++;
+    if (g->script) {
+        for (int i = 0; i < n; ++i) out[i] = g->script[g->script_pos++];
+        return;
     }
-    return u32_to_uniform(g->blk[g->idx++ & 3u]);
+    uint32_t c[4] = {c0, ((uint32_t)purpose << 24) | g->bounce, g->pixel, g->sample}, w[4];
+    philox4x32_10(c, g->key, w);
+    if (g->st) g->st->philox_blocks++;
+    for (int i = 0; i < n; ++i) out[i] = u32_to_uniform(w[i]);
 }
 static float rng_medium(Rng* g, int slot)           /* the draw of Volumes.cuh:40 */
 {
-    uint32_t c[4] = {g->bounce, 1u + (uint32_t)slot, g->pixel, g->sample}, o[4];
-    philox4x32_10(c, g->key, o);
-    if (g->st) g->st->philox_blocks++;
-    return u32_to_uniform(o[0]);
+    float x;
+    rng_draw(g, RNG_MEDIUM, (uint32_t)slot, 1, &x);
+    return x;
 }
 
 /* ------------------------------------------------------------- geometry ---- */
@@ -237,7 +250,7 @@ static int hit_box(const rt_object* o, const Ray* r, float t0, float t1, Hit* re
     int any = 0;
     float closest = t1;
     for (int i = 0; i < 6; ++i) {            /* HitableList::hit, HitableList.cuh:17-32 */
-        if (st) st->prim_tests++;
+        if (st) { st->prim_tests++; st->rect_tests++; }
         if (hit_rect(types[i], faces[i], r, t0, closest, &temp)) {
             if (i & 1) temp.front_face = !temp.front_face;
             any = 1;
@@ -369,7 +382,12 @@ static int hit_bare(const Ctx* c, int oi, const Ray* r, float tMin, float tMax, 
 {
     const rt_object* o = &c->s->objects[oi];
     int h = 0;
-    if (c->st && o->type != RT_OBJ_GROUP && o->type != RT_OBJ_BOX) c->st->prim_tests++;
+    if (c->st && o->type != RT_OBJ_GROUP && o->type != RT_OBJ_BOX) {
+        c->st->prim_tests++;
+        if (o->type == RT_OBJ_SPHERE || o->type == RT_OBJ_MOVING_SPHERE) c->st->sphere_tests++;
+        else if (o->type == RT_OBJ_TRIANGLE) c->st->tri_tests++;
+        else if (o->type != RT_OBJ_MEDIUM) c->st->rect_tests++;
+    }
     switch (o->type) {
     case RT_OBJ_SPHERE:        h = hit_sphere(o, r, tMin, tMax, rec); break;
     case RT_OBJ_MOVING_SPHERE: h = hit_moving_sphere(o, r, tMin, tMax, rec); break;
@@ -396,6 +414,7 @@ static int hit_chain(const Ctx* c, int oi, int k, const Ray* r, float tMin, floa
     const rt_object* o = &c->s->objects[oi];
     if (k == o->op_count) return hit_bare(c, oi, r, tMin, tMax, rec);
     const rt_xform_op* op = &c->s->ops[o->op_begin + k];
+    if (c->st) { if (op->type == RT_OP_TRANSLATE) c->st->trans_ops++; else c->st->rot_ops++; }
     if (op->type == RT_OP_TRANSLATE) {
         V3 offset = v3(op->a, op->b, op->c);
         Ray moved = {vsub(r->A, offset), r->B, r->time};
@@ -480,9 +499,11 @@ static int refract(V3 v, V3 n, float niOverNt, V3* refracted)                   
 static V3 random_in_unit_sphere(Rng* g)                                                /* :34-40 */
 {
     V3 p;
+    uint32_t k = 0;
     do {
-        float a = rng_next(g), b = rng_next(g), c = rng_next(g);
-        p = vsub(vscale(2.f, v3(a, b, c)), v3(1.f, 1.f, 1.f));
+        float x[3];
+        rng_draw(g, RNG_SPHERE, k++, 3, x);
+        p = vsub(vscale(2.f, v3(x[0], x[1], x[2])), v3(1.f, 1.f, 1.f));
         if (g->st) g->st->sphere_iters++;
     } while (vsqlen(p) >= 1.f);
     return p;
@@ -537,7 +558,9 @@ static int scatter(const rt_flat_scene* s, int mi, const Ray* rIn, const Hit* re
         if (refract(rIn->B, outwardNorm, niOverNt, &refracted)) reflectProb = schlick(cosine, refIdx);
         else reflectProb = 1.f;
         scattered->A = rec->p; scattered->time = rIn->time;
-        if (rng_next(g) < reflectProb) scattered->B = reflected;
+        float xi;
+        rng_draw(g, RNG_GLASS, 0, 1, &xi);
+        if (xi < reflectProb) scattered->B = reflected;
         else scattered->B = refracted;
         return 1;
     }
@@ -557,17 +580,19 @@ static V3 ld3(const float* f) { return v3(f[0], f[1], f[2]); }
 static V3 random_in_unit_disk(Rng* g)                                                  /* Camera.cuh:12-18 */
 {
     V3 p;
+    uint32_t k = 0;
     do {
-        float a = rng_next(g), b = rng_next(g);
-        p = vsub(vscale(2.0f, v3(a, b, 0)), v3(1.f, 1.f, 0.f));
+        float x[2];
+        rng_draw(g, RNG_DISK, k++, 2, x);
+        p = vsub(vscale(2.0f, v3(x[0], x[1], 0)), v3(1.f, 1.f, 0.f));
     } while (vdot(p, p) > 1.f);
     return p;
 }
-static Ray generate_ray(const rt_camera* c, float s, float t, Rng* g)                   /* Camera.cuh:40-46 */
+static Ray generate_ray(const rt_camera* c, float s, float t, float xi_time, Rng* g)     /* Camera.cuh:40-46 */
 {
     V3 rd = vscale(c->lens_radius, random_in_unit_disk(g));
     V3 offset = vadd(vscale(rd.e[0], ld3(c->u)), vscale(rd.e[1], ld3(c->v)));
-    float time = c->time0 + rng_next(g) * (c->time1 - c->time0);
+    float time = c->time0 + xi_time * (c->time1 - c->time0);
     Ray r;
     r.A = vadd(ld3(c->origin), offset);
     r.B = vsub(vsub(vadd(vadd(ld3(c->lower_left), vscale(s, ld3(c->horizontal))), vscale(t, ld3(c->vertical))), ld3(c->origin)), offset);
@@ -694,7 +719,7 @@ void rto_texture_value(const rt_flat_scene* s, int texture, int n, const float* 
 }
 
 void rto_scatter(const rt_flat_scene* s, int material, int n, const float* ray_in, const float* rec_in,
-                 uint64_t seed, const uint32_t* pixel_sample, rto_scatter_out* out)
+                 const float* xi, int xi_stride, rto_scatter_out* out)
 {
     for (int i = 0; i < n; ++i) {
         const float* q = ray_in + 7 * (size_t)i;
@@ -707,7 +732,8 @@ void rto_scatter(const rt_flat_scene* s, int material, int n, const float* ray_i
         rec.normal = v3(h[6], h[7], h[8]);
         rec.material = material;
         Rng g;
-        rng_init(&g, seed, pixel_sample[2 * i], pixel_sample[2 * i + 1], NULL);
+        rng_init(&g, 0, 0, 0, NULL);
+        g.script = xi + (size_t)i * xi_stride;   /* uniforms in the order the reference consumes them */
         V3 att = v3(0, 0, 0);
         Ray sc = {v3(0, 0, 0), v3(0, 0, 0), 0.f};
         V3 em = emitted(s, material, rec.u, rec.v, rec.p);
@@ -720,7 +746,7 @@ void rto_scatter(const rt_flat_scene* s, int material, int n, const float* ray_i
             o->emitted[k] = em.e[k];
         }
         o->time = sc.time;
-        o->draws = g.idx;
+        o->draws = g.script_pos;
     }
 }
 
@@ -729,19 +755,28 @@ void rto_camera_rays(const rt_flat_scene* s, int n, const float* st, uint64_t se
 {
     for (int i = 0; i < n; ++i) {
         Rng g;
+        float cam[3];
         rng_init(&g, seed, pixel_sample[2 * i], pixel_sample[2 * i + 1], NULL);
-        Ray r = generate_ray(&s->camera, st[2 * i], st[2 * i + 1], &g);
+        rng_draw(&g, RNG_CAMERA, 0, 3, cam);
+        Ray r = generate_ray(&s->camera, st[2 * i], st[2 * i + 1], cam[2], &g);
         float* q = rays_out + 7 * (size_t)i;
         for (int k = 0; k < 3; ++k) { q[k] = r.A.e[k]; q[3 + k] = r.B.e[k]; }
         q[6] = r.time;
     }
 }
 
+/* n uniforms of the rocRAND-compatible sequential stream (seed, subsequence = pixel | sample<<32,
+ * offset 0): word i&3 of block (i>>2, 0, pixel, sample) */
 void rto_uniforms(uint64_t seed, uint32_t pixel, uint32_t sample, int n, float* out)
 {
-    Rng g;
-    rng_init(&g, seed, pixel, sample, NULL);
-    for (int i = 0; i < n; ++i) out[i] = rng_next(&g);
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, w[4];
+    for (int i = 0; i < n; ++i) {
+        if ((i & 3) == 0) {
+            uint32_t c[4] = {(uint32_t)i >> 2, 0u, pixel, sample};
+            philox4x32_10(c, key, w);
+        }
+        out[i] = u32_to_uniform(w[i & 3]);
+    }
 }
 
 void rto_philox_block(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
@@ -770,11 +805,13 @@ static void* render_rows(void* arg)
             V3 sum = v3(0, 0, 0);
             for (int sidx = jb->s_begin; sidx < jb->s_end; ++sidx) {
                 Rng g;
+                float cam[3];
                 rng_init(&g, jb->seed, pixel, (uint32_t)sidx, &jb->st);
                 c.rng = &g;
-                float u = (float)(i + rng_next(&g)) / (float)jb->W;     /* main.cu:185 */
-                float v = (float)(j + rng_next(&g)) / (float)jb->H;     /* main.cu:186 */
-                Ray r = generate_ray(&jb->s->camera, u, v, &g);
+                rng_draw(&g, RNG_CAMERA, 0, 3, cam);
+                float u = (float)(i + cam[0]) / (float)jb->W;           /* main.cu:185 */
+                float v = (float)(j + cam[1]) / (float)jb->H;           /* main.cu:186 */
+                Ray r = generate_ray(&jb->s->camera, u, v, cam[2], &g);
                 V3 col = colour(&c, r, jb->max_depth, jb->background, &g, &jb->st.rays);
                 sum = vadd(sum, col);                                   /* outCol += ... main.cu:188 */
                 jb->st.samples++;
@@ -807,6 +844,8 @@ void rto_render(const rt_flat_scene* s, int W, int H, int s_begin, int s_end, ui
         tot.rays += jobs[k].st.rays; tot.samples += jobs[k].st.samples;
         tot.prim_tests += jobs[k].st.prim_tests; tot.nodes_visited += jobs[k].st.nodes_visited;
         tot.philox_blocks += jobs[k].st.philox_blocks; tot.sphere_iters += jobs[k].st.sphere_iters;
+        tot.rect_tests += jobs[k].st.rect_tests; tot.sphere_tests += jobs[k].st.sphere_tests;
+        tot.tri_tests += jobs[k].st.tri_tests; tot.rot_ops += jobs[k].st.rot_ops; tot.trans_ops += jobs[k].st.trans_ops;
     }
     if (st_out) *st_out = tot;
     free(jobs);

@@ -28,7 +28,7 @@ typedef struct rto_scatter_out {
     float   direction[3];
     float   time;
     float   emitted[3];
-    uint32_t draws;      /* uniforms consumed from the path stream */
+    uint32_t draws;      /* uniforms consumed */
 } rto_scatter_out;       /* 60 bytes */
 
 typedef struct rto_stats {
@@ -38,6 +38,11 @@ typedef struct rto_stats {
     uint64_t nodes_visited; /* BVH nodes popped (use_bvh only) */
     uint64_t philox_blocks;
     uint64_t sphere_iters;  /* randomInUnitSphere rejection iterations */
+    uint64_t rect_tests;    /* split of prim_tests by kind (a Box adds 6 rect tests) */
+    uint64_t sphere_tests;
+    uint64_t tri_tests;
+    uint64_t rot_ops;       /* RotateY / Translate wrappers applied to a ray */
+    uint64_t trans_ops;
 } rto_stats;
 
 void rto_trace_rays(const rt_flat_scene* s, int n, const float* rays7, float tmin, float tmax,
@@ -47,8 +52,9 @@ void rto_object_hit(const rt_flat_scene* s, int object, int n, const float* rays
 void rto_trace_primary(const rt_flat_scene* s, int W, int H, float s_off, float t_off, int use_bvh,
                        int32_t* prim, float* t_out);
 void rto_texture_value(const rt_flat_scene* s, int texture, int n, const float* uvp5, float* rgb);
+/* xi: per call, xi_stride scripted uniforms consumed in the order the reference's scatter() draws them */
 void rto_scatter(const rt_flat_scene* s, int material, int n, const float* ray_in7, const float* rec_in9,
-                 uint64_t seed, const uint32_t* pixel_sample, rto_scatter_out* out);
+                 const float* xi, int xi_stride, rto_scatter_out* out);
 void rto_camera_rays(const rt_flat_scene* s, int n, const float* st, uint64_t seed,
                      const uint32_t* pixel_sample, float* rays_out7);
 void rto_uniforms(uint64_t seed, uint32_t pixel, uint32_t sample, int n, float* out);

@@ -1,0 +1,93 @@
+"""The C-ABI library loads, exports what include/rt_api.h declares, and its host-only entry points
+behave (no GPU needed)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rt_api.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(binding):
+    lib = binding.load_library()
+    names = declared_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), "librt_amd.so does not export %s" % n
+    assert sorted(binding.EXPORTS) == names
+
+
+def test_struct_layouts(binding):
+    assert C.sizeof(binding.RtObject) == 104
+    assert C.sizeof(binding.RtXformOp) == 16
+    assert C.sizeof(binding.RtMaterial) == 16
+    assert C.sizeof(binding.RtTexture) == 40
+    assert C.sizeof(binding.RtCamera) == 96          # same members as the reference Camera
+    assert C.sizeof(binding.RtBvhNode) == 32
+    assert C.sizeof(binding.RtHitRecord) == 52
+    assert np.dtype(binding.HIT_DTYPE).itemsize == 52
+
+
+def test_unknown_scene_is_an_error_not_an_exit(binding):
+    with pytest.raises(binding.RtError) as e:
+        binding.Scene("no_such_scene", 8, 8)
+    assert "unknown built-in scene" in str(e.value)
+    with pytest.raises(binding.RtError):
+        binding.Scene("cornell", 0, 8)
+
+
+def test_quantise_flips_rows_and_clamps(binding):
+    lib = binding.lib()
+    W, H = 3, 2
+    rgb = np.zeros((H, W, 3), np.float32)
+    rgb[0, 0] = [0.0, 0.5, 1.0]      # bottom-left
+    rgb[1, 2] = [2.0, -1.0, np.nan]  # top-right: above 1 must clamp (the reference wraps, main.cu:688-694)
+    out = np.zeros((H, W, 3), np.uint8)
+    assert lib.rt_quantise_rgb8(rgb.ctypes.data, W, H, out.ctypes.data) == 0
+    assert out[1, 0].tolist() == [0, int(255.99 * 0.5), 255]      # bottom row comes out last
+    assert out[0, 2].tolist() == [255, 0, 0]
+    assert lib.rt_quantise_rgb8(None, W, H, out.ctypes.data) < 0
+
+
+def test_write_ppm(binding, tmp_path):
+    lib = binding.lib()
+    img = (np.arange(4 * 2 * 3) % 256).astype(np.uint8)
+    p = str(tmp_path / "x.ppm").encode()
+    assert lib.rt_write_ppm(p, img.ctypes.data, 4, 2) == 0
+    data = open(p, "rb").read()
+    assert data.startswith(b"P6\n4 2\n255\n") and data.endswith(img.tobytes())
+    assert lib.rt_write_ppm(b"/nonexistent_dir/x.ppm", img.ctypes.data, 4, 2) < 0
+    assert b"cannot open" in lib.rt_last_error()
+
+
+def test_from_flat_round_trip_and_validation(binding, oracle_mod):
+    sc = binding.Scene("kat", 32, 24)
+    h = C.c_void_p()
+    assert binding.lib().rt_scene_from_flat(sc.flat, C.byref(h)) == 0
+    copy = binding.lib().rt_scene_flat(h)
+    assert oracle_mod.scene_digest(copy) == oracle_mod.scene_digest(sc.flat)
+    binding.lib().rt_scene_destroy(h)
+    # corrupt one index at a time: each must be refused on the host
+    f = sc.flat.contents
+    first = [f.objects[i] for i in range(f.n_objects) if f.objects[i].type < 7][0]   # some surface
+    for field, bad in [("material", 10 ** 6), ("op_begin", 10 ** 6), ("type", 99)]:
+        keep = getattr(first, field)
+        setattr(first, field, bad)
+        h2 = C.c_void_p()
+        rc = binding.lib().rt_scene_from_flat(sc.flat, C.byref(h2))
+        setattr(first, field, keep)
+        assert rc < 0, "corrupted %s accepted" % field
+        assert b"invalid scene" in binding.lib().rt_last_error()
+    keep = f.bvh_items[0]
+    f.bvh_items[0] = 10 ** 6
+    h3 = C.c_void_p()
+    assert binding.lib().rt_scene_from_flat(sc.flat, C.byref(h3)) < 0
+    f.bvh_items[0] = keep
