@@ -99,7 +99,8 @@ __global__ __launch_bounds__(RT_BLOCK) void render_kernel(DScene S, int W, int H
     const uint32_t pixel = (uint32_t)(j * W + i);
 
     V3 sum = mk(0.f, 0.f, 0.f);
-    uint32_t s = valid ? s_begin : s_end;
+    /* depth 0: colour()'s loop body never runs and every sample is black (main.cu:53,71) */
+    uint32_t s = (valid && max_depth > 0) ? s_begin : s_end;
     bool alive = false;
     DRay ray = {mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f), 0.f};
     V3 att = mk(1.f, 1.f, 1.f), emi = mk(0.f, 0.f, 0.f);

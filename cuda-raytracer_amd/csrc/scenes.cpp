@@ -163,10 +163,12 @@ Built bvh_boxes(int width, int height)
         }
     Hitable** list = ptr_array(2);
     list[0] = new BvhNode(boxes, n, 0, 1, &rng);
-    list[1] = new Sphere(Vector3(0, 10, 0), 1, new DiffuseLight(new ConstantTexture(Vector3(8, 8, 8))));
+    list[1] = new Sphere(Vector3(-800, 400, -800), 120, new DiffuseLight(new ConstantTexture(Vector3(8, 8, 8))));
     Built b;
     b.world = new HitableList(list, 2);
-    b.cam = look(Vector3(13, 2, 3), Vector3(0, 0, 0), 20.f, width, height, 0.f, 10.f);
+    /* main.cu:339-340 looks from (13,2,3) at the origin and sees none of the boxes; the camera is moved
+     * so that they are in view */
+    b.cam = look(Vector3(-800, 320, -1350), Vector3(-800, 40, -800), 40.f, width, height, 0.f, 10.f);
     return b;
 }
 
