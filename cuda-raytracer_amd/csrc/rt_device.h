@@ -63,6 +63,7 @@ struct HitLite {
     float   t;
     int32_t obj;   /* winning leaf object, -1 = miss */
     int32_t grp;   /* group object it was reached through, -1 = directly in the world list */
+    int32_t aux;   /* Box: which of the six faces produced t */
 };
 
 /* the rebuilt record (Intersect, Hitable.cuh:10-22) */
@@ -129,12 +130,13 @@ __device__ __forceinline__ bool rect_t(float a0, float a1, float b0, float b1, f
     float ob = KA == 2 ? r.o.y : r.o.z;
     float db = KA == 2 ? r.d.y : r.d.z;
     float t = (k - ok) / dk;
-    if (t < t0 || t > t1) return false;
     float a = oa + t * da;
     float b = ob + t * db;
-    if (a < a0 || a > a1 || b < b0 || b > b1) return false;
+    /* the reference's two early returns, evaluated without branching: same comparisons, same result
+     * (NaNs fail none of the reject tests, exactly as in `if (t<t0 || t>t1) return false`) */
+    bool reject = (t < t0) | (t > t1) | (a < a0) | (a > a1) | (b < b0) | (b > b1);
     t_out = t;
-    return true;
+    return !reject;
 }
 __device__ __forceinline__ bool rect_any_t(int type, const float* f, const DRay& r, float t0, float t1, float& t)
 {
@@ -168,13 +170,23 @@ __device__ __forceinline__ bool box_t(const float* f, const DRay& r, float t0, f
 {
     bool any = false;
     float closest = t1, t;
-    if (rect_t<2>(f[0], f[3], f[1], f[4], f[5], r, t0, closest, t)) { any = true; closest = t; face = 0; }
-    if (rect_t<2>(f[0], f[3], f[1], f[4], f[2], r, t0, closest, t)) { any = true; closest = t; face = 1; }
-    if (rect_t<1>(f[0], f[3], f[2], f[5], f[4], r, t0, closest, t)) { any = true; closest = t; face = 2; }
-    if (rect_t<1>(f[0], f[3], f[2], f[5], f[1], r, t0, closest, t)) { any = true; closest = t; face = 3; }
-    if (rect_t<0>(f[1], f[4], f[2], f[5], f[3], r, t0, closest, t)) { any = true; closest = t; face = 4; }
-    if (rect_t<0>(f[1], f[4], f[2], f[5], f[0], r, t0, closest, t)) { any = true; closest = t; face = 5; }
+    int fc = 0;
+#define RT_FACE(KA, A0, A1, B0, B1, K, ID)                                              \
+    {                                                                                   \
+        bool h_ = rect_t<KA>(A0, A1, B0, B1, K, r, t0, closest, t);                     \
+        any |= h_;                                                                      \
+        closest = h_ ? t : closest;                                                     \
+        fc = h_ ? ID : fc;                                                              \
+    }
+    RT_FACE(2, f[0], f[3], f[1], f[4], f[5], 0)
+    RT_FACE(2, f[0], f[3], f[1], f[4], f[2], 1)
+    RT_FACE(1, f[0], f[3], f[2], f[5], f[4], 2)
+    RT_FACE(1, f[0], f[3], f[2], f[5], f[1], 3)
+    RT_FACE(0, f[1], f[4], f[2], f[5], f[3], 4)
+    RT_FACE(0, f[1], f[4], f[2], f[5], f[0], 5)
+#undef RT_FACE
     t_out = closest;
+    face = fc;
     return any;
 }
 
@@ -218,25 +230,26 @@ __device__ __forceinline__ void apply_chain(const DScene& S, int begin, int coun
 }
 
 /* bare primitive (ray already in the object's frame): t only */
-__device__ __forceinline__ bool prim_t(const DObj& o, const DRay& r, float tMin, float tMax, float& t)
+__device__ __forceinline__ bool prim_t(const DObj& o, const DRay& r, float tMin, float tMax, float& t, int& aux)
 {
+    aux = 0;
     switch (o.type) {
     case RT_OBJ_SPHERE:        return sphere_t(ld3(o.f), o.f[3], r, tMin, tMax, t);
     case RT_OBJ_MOVING_SPHERE: return sphere_t(moving_centre(o.f, r.time), o.f[8], r, tMin, tMax, t);
     case RT_OBJ_RECT_XY:
     case RT_OBJ_RECT_XZ:
     case RT_OBJ_RECT_YZ:       return rect_any_t(o.type, o.f, r, tMin, tMax, t);
-    case RT_OBJ_BOX: { int face; return box_t(o.f, r, tMin, tMax, t, face); }
+    case RT_OBJ_BOX:           return box_t(o.f, r, tMin, tMax, t, aux);
     case RT_OBJ_TRIANGLE:      return triangle_t(o.f, r, tMin, tMax, t);
     default: return false;
     }
 }
 
 /* leaf with its own wrapper chain */
-__device__ __forceinline__ bool leaf_t(const DScene& S, const DObj& o, DRay r, float tMin, float tMax, float& t)
+__device__ __forceinline__ bool leaf_t(const DScene& S, const DObj& o, DRay r, float tMin, float tMax, float& t, int& aux)
 {
     apply_chain(S, o.op_begin, o.op_count, r);
-    return prim_t(o, r, tMin, tMax, t);
+    return prim_t(o, r, tMin, tMax, t, aux);
 }
 
 /* ConstantMedium::hit Volumes.cuh:26-49 (ray already in the medium's frame) */
@@ -245,8 +258,9 @@ __device__ __forceinline__ bool medium_t(const DScene& S, const DObj& o, const D
 {
     const DObj& b = S.objs[o.child_begin];
     float t1, t2;
-    if (!leaf_t(S, b, r, -FLT_MAX, FLT_MAX, t1)) return false;
-    if (!leaf_t(S, b, r, t1 + .0001f, FLT_MAX, t2)) return false;
+    int unused;
+    if (!leaf_t(S, b, r, -FLT_MAX, FLT_MAX, t1, unused)) return false;
+    if (!leaf_t(S, b, r, t1 + .0001f, FLT_MAX, t2, unused)) return false;
     if (t1 < tMin) t1 = tMin;
     if (t2 > tMax) t2 = tMax;
     if (t1 >= t2) return false;
@@ -290,8 +304,8 @@ __device__ __forceinline__ void group_closest(const DScene& S, int gi, const DOb
                 if (n.count) {
                     for (uint32_t i = 0; i < n.count; ++i) {
                         int oi = S.items[n.left_first + i];
-                        float t;
-                        if (leaf_t(S, S.objs[oi], r, tMin, best.t, t)) { best.t = t; best.obj = oi; best.grp = gi; }
+                        float t; int aux;
+                        if (leaf_t(S, S.objs[oi], r, tMin, best.t, t, aux)) { best.t = t; best.obj = oi; best.grp = gi; best.aux = aux; }
                     }
                 } else {
                     /* nearer child first (by box centre along the ray), other one on the stack */
@@ -318,14 +332,14 @@ __device__ __forceinline__ void group_closest(const DScene& S, int gi, const DOb
     for (int i = 0; i < g.child_count; ++i) {
         int oi = g.child_begin + i;
         const DObj& o = S.objs[oi];
-        float t;
+        float t; int aux;
         if (o.type == RT_OBJ_MEDIUM) {
             if (rng) {
                 DRay rm = r;
                 apply_chain(S, o.op_begin, o.op_count, rm);
-                if (medium_t(S, o, rm, tMin, best.t, *rng, bounce, t)) { best.t = t; best.obj = oi; best.grp = gi; }
+                if (medium_t(S, o, rm, tMin, best.t, *rng, bounce, t)) { best.t = t; best.obj = oi; best.grp = gi; best.aux = 0; }
             }
-        } else if (leaf_t(S, o, r, tMin, best.t, t)) { best.t = t; best.obj = oi; best.grp = gi; }
+        } else if (leaf_t(S, o, r, tMin, best.t, t, aux)) { best.t = t; best.obj = oi; best.grp = gi; best.aux = aux; }
     }
 }
 
@@ -334,7 +348,7 @@ template <bool HAS_BVH>
 __device__ __forceinline__ HitLite closest_hit(const DScene& S, const DRay& r, float tMin, float tMax,
                                                const PathRng* rng, uint32_t bounce, int* stack)
 {
-    HitLite best = {tMax, -1, -1};
+    HitLite best = {tMax, -1, -1, 0};
     const DObj& w = S.objs[S.world];
     if (HAS_BVH && w.bvh_root >= 0) {
         group_closest<HAS_BVH>(S, -1, w, r, tMin, best, rng, bounce, stack);
@@ -343,16 +357,16 @@ __device__ __forceinline__ HitLite closest_hit(const DScene& S, const DRay& r, f
     for (int i = 0; i < w.child_count; ++i) {
         int oi = w.child_begin + i;
         const DObj& o = S.objs[oi];
-        float t;
+        float t; int aux;
         if (o.type == RT_OBJ_GROUP) {
             group_closest<HAS_BVH>(S, oi, o, r, tMin, best, rng, bounce, stack);
         } else if (o.type == RT_OBJ_MEDIUM) {
             if (rng) {
                 DRay rm = r;
                 apply_chain(S, o.op_begin, o.op_count, rm);
-                if (medium_t(S, o, rm, tMin, best.t, *rng, bounce, t)) { best.t = t; best.obj = oi; best.grp = -1; }
+                if (medium_t(S, o, rm, tMin, best.t, *rng, bounce, t)) { best.t = t; best.obj = oi; best.grp = -1; best.aux = 0; }
             }
-        } else if (leaf_t(S, o, r, tMin, best.t, t)) { best.t = t; best.obj = oi; best.grp = -1; }
+        } else if (leaf_t(S, o, r, tMin, best.t, t, aux)) { best.t = t; best.obj = oi; best.grp = -1; best.aux = aux; }
     }
     return best;
 }
@@ -399,10 +413,7 @@ __device__ __forceinline__ void rebuild(const DScene& S, const DRay& world_ray, 
     case RT_OBJ_RECT_YZ: rect_rec<0>(o.f[0], o.f[1], o.f[2], o.f[3], r, t, h); break;
     case RT_OBJ_BOX: {
         const float* f = o.f;
-        /* re-run the six faces bounded (inclusively) by the winning t: nothing nearer exists, so the
-         * face that survives is the one that produced t in the search */
-        float tt; int face = 0;
-        box_t(f, r, tMin, t, tt, face);
+        const int face = hl.aux;      /* the face whose test produced t in the search */
         switch (face) {
         case 0: case 1: rect_rec<2>(f[0], f[3], f[1], f[4], r, t, h); break;
         case 2: case 3: rect_rec<1>(f[0], f[3], f[2], f[5], r, t, h); break;
