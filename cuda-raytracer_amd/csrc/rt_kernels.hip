@@ -20,6 +20,10 @@
 #include "rt_device.h"
 #include "rt_host.h"
 
+#ifndef RT_RENDER_WAVES
+#define RT_RENDER_WAVES 4      /* waves per SIMD the render kernel is compiled for (<=128 VGPRs) */
+#endif
+
 /* ------------------------------------------------------------------ kernels -- */
 template <bool HAS_BVH>
 __global__ __launch_bounds__(RT_BLOCK) void trace_rays_kernel(DScene S, int n, const float* __restrict__ rays,
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(RT_BLOCK) void trace_primary_kernel(DScene S, int W
 }
 
 template <bool HAS_BVH, int BG>
-__global__ __launch_bounds__(RT_BLOCK) void render_kernel(DScene S, int W, int H, uint32_t s_begin, uint32_t s_end,
+__global__ __launch_bounds__(RT_BLOCK, RT_RENDER_WAVES) void render_kernel(DScene S, int W, int H, uint32_t s_begin, uint32_t s_end,
                                                            uint32_t k0, uint32_t k1, int max_depth,
                                                            float* __restrict__ accum,
                                                            unsigned long long* __restrict__ counters)
