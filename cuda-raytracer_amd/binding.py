@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")   # RT_AMD_LIB: diagnostic builds (tools/diag)
 
 RT_BG_BLACK, RT_BG_SKY = 0, 1
 

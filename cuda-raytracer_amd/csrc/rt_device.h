@@ -22,7 +22,6 @@
 #include "rt_host.h"
 
 #define RT_PI_D 3.14159265358979323846
-#define RT_STACK_DEPTH 48        /* per-lane BVH stack entries (LDS) */
 #define RT_BLOCK 256
 
 struct DScene {
@@ -31,12 +30,16 @@ struct DScene {
     const rt_material* __restrict__ mats;
     const rt_texture*  __restrict__ texs;
     const uint8_t*     __restrict__ image;
-    const rt_bvh_node* __restrict__ nodes;
-    const int32_t*     __restrict__ items;
+    const DNode*       __restrict__ nodes;   /* 64-byte two-box nodes (rt_host.h) */
+    const DObj*        __restrict__ leafs;   /* BVH leaf table: first 64 bytes of each row are read */
     int32_t world;
     int32_t n_media;
     rt_camera cam;
 };
+
+__device__ __forceinline__ int      obj_type(uint32_t head)     { return (int)(head & 0xffu); }
+__device__ __forceinline__ uint32_t obj_flags(uint32_t head)    { return (head >> 8) & 0xffu; }
+__device__ __forceinline__ int      obj_op_count(uint32_t head) { return (int)((head >> 16) & 0xffu); }
 
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 mk(float a, float b, float c) { V3 r = {a, b, c}; return r; }
@@ -144,24 +147,30 @@ __device__ __forceinline__ bool rect_any_t(int type, const float* f, const DRay&
     if (type == RT_OBJ_RECT_XZ) return rect_t<1>(f[0], f[1], f[2], f[3], f[4], r, t0, t1, t);
     return rect_t<0>(f[0], f[1], f[2], f[3], f[4], r, t0, t1, t);
 }
-/* record of a rect hit at t: u,v,p and the ray-facing axis normal (setFaceNormal, Hitable.cuh:17-21) */
-template <int KA>
-__device__ __forceinline__ void rect_rec(float a0, float a1, float b0, float b1, const DRay& r, float t, HitRec& h)
+/* record of a rect hit at t: u,v,p and the ray-facing axis normal (setFaceNormal, Hitable.cuh:17-21).
+ * The fixed axis KA is a run-time value picked with selects, not a template argument: the winners of the
+ * lanes of a wave are rects of all three kinds and box faces, and one branch-free body serves them all
+ * (a switch over the kinds ran every arm for a sixth of the lanes each). */
+template <bool WANT_UV>
+__device__ __forceinline__ void rect_rec(int KA, float a0, float a1, float b0, float b1, const DRay& r, float t, bool want_uv, HitRec& h)
 {
     float oa = KA == 0 ? r.o.y : r.o.x;
     float da = KA == 0 ? r.d.y : r.d.x;
     float ob = KA == 2 ? r.o.y : r.o.z;
     float db = KA == 2 ? r.d.y : r.d.z;
     float dk = KA == 2 ? r.d.z : (KA == 1 ? r.d.y : r.d.x);
-    float a = oa + t * da;
-    float b = ob + t * db;
-    h.u = (a - a0) / (a1 - a0);
-    h.v = (b - b0) / (b1 - b0);
+    if (WANT_UV || want_uv) {
+        float a = oa + t * da;
+        float b = ob + t * db;
+        h.u = (a - a0) / (a1 - a0);
+        h.v = (b - b0) / (b1 - b0);
+    }
     h.t = t;
     h.p = at(r, t);
     bool front = dk < 0;           /* dot(dir, +axis) < 0 */
     float s = front ? 1.f : -1.f;
-    h.n = mk(KA == 0 ? s : (front ? 0.f : -0.f), KA == 1 ? s : (front ? 0.f : -0.f), KA == 2 ? s : (front ? 0.f : -0.f));
+    float z = front ? 0.f : -0.f;
+    h.n = mk(KA == 0 ? s : z, KA == 1 ? s : z, KA == 2 ? s : z);
     h.front = front;
 }
 
@@ -213,34 +222,47 @@ __device__ __forceinline__ bool triangle_t(const float* f, const DRay& r, float 
 
 /* ------------------------------------------------------------ transforms ---- */
 /* Translate::hit Transform.cuh:19-28 and RotateY::hit :90-112, ray side */
-__device__ __forceinline__ void apply_op(const rt_xform_op& op, DRay& r)
+__device__ __forceinline__ void apply_op(int type, float a, float b, float c3, DRay& r)
 {
-    if (op.type == RT_OP_TRANSLATE) {
-        r.o = r.o - mk(op.a, op.b, op.c);
+    if (type == RT_OP_TRANSLATE) {
+        r.o = r.o - mk(a, b, c3);
     } else {
-        float s = op.a, c = op.b;
+        float s = a, c = b;
         float ox = c * r.o.x - s * r.o.z, oz = s * r.o.x + c * r.o.z;
         float dx = c * r.d.x - s * r.d.z, dz = s * r.d.x + c * r.d.z;
         r.o.x = ox; r.o.z = oz; r.d.x = dx; r.d.z = dz;
     }
 }
-__device__ __forceinline__ void apply_chain(const DScene& S, int begin, int count, DRay& r)
+/* k-th wrapper op of object o, outermost first: the first two sit in the row itself */
+struct OpV { int type; float a, b, c; };
+__device__ __forceinline__ OpV obj_op(const DScene& S, const DObj& o, int k)
 {
-    for (int k = 0; k < count; ++k) apply_op(S.ops[begin + k], r);
+    OpV v;
+    if (k == 0) { v.type = (int)((o.head >> 24) & 0xfu); v.a = o.op0[0]; v.b = o.op0[1]; v.c = o.op0[2]; }
+    else if (k == 1) { v.type = (int)((o.head >> 28) & 0xfu); v.a = o.op1[0]; v.b = o.op1[1]; v.c = o.op1[2]; }
+    else { const rt_xform_op p = S.ops[o.op_begin + k]; v.type = p.type; v.a = p.a; v.b = p.b; v.c = p.c; }
+    return v;
+}
+__device__ __forceinline__ void apply_chain(const DScene& S, const DObj& o, DRay& r)
+{
+    const int n = obj_op_count(o.head);
+    if (n > 0) apply_op((int)((o.head >> 24) & 0xfu), o.op0[0], o.op0[1], o.op0[2], r);
+    if (n > 1) apply_op((int)((o.head >> 28) & 0xfu), o.op1[0], o.op1[1], o.op1[2], r);
+    for (int k = 2; k < n; ++k) { const rt_xform_op p = S.ops[o.op_begin + k]; apply_op(p.type, p.a, p.b, p.c, r); }
 }
 
 /* bare primitive (ray already in the object's frame): t only */
-__device__ __forceinline__ bool prim_t(const DObj& o, const DRay& r, float tMin, float tMax, float& t, int& aux)
+__device__ __forceinline__ bool prim_t(int type, const float* f, const DRay& r, float tMin, float tMax, float& t, int& aux)
 {
     aux = 0;
-    switch (o.type) {
-    case RT_OBJ_SPHERE:        return sphere_t(ld3(o.f), o.f[3], r, tMin, tMax, t);
-    case RT_OBJ_MOVING_SPHERE: return sphere_t(moving_centre(o.f, r.time), o.f[8], r, tMin, tMax, t);
+    switch (type) {
+    case RT_OBJ_SPHERE:        return sphere_t(ld3(f), f[3], r, tMin, tMax, t);
+    case RT_OBJ_MOVING_SPHERE: return sphere_t(moving_centre(f, r.time), f[8], r, tMin, tMax, t);
     case RT_OBJ_RECT_XY:
     case RT_OBJ_RECT_XZ:
-    case RT_OBJ_RECT_YZ:       return rect_any_t(o.type, o.f, r, tMin, tMax, t);
-    case RT_OBJ_BOX:           return box_t(o.f, r, tMin, tMax, t, aux);
-    case RT_OBJ_TRIANGLE:      return triangle_t(o.f, r, tMin, tMax, t);
+    case RT_OBJ_RECT_YZ:       return rect_any_t(type, f, r, tMin, tMax, t);
+    case RT_OBJ_BOX:           return box_t(f, r, tMin, tMax, t, aux);
+    case RT_OBJ_TRIANGLE:      return triangle_t(f, r, tMin, tMax, t);
     default: return false;
     }
 }
@@ -248,8 +270,8 @@ __device__ __forceinline__ bool prim_t(const DObj& o, const DRay& r, float tMin,
 /* leaf with its own wrapper chain */
 __device__ __forceinline__ bool leaf_t(const DScene& S, const DObj& o, DRay r, float tMin, float tMax, float& t, int& aux)
 {
-    apply_chain(S, o.op_begin, o.op_count, r);
-    return prim_t(o, r, tMin, tMax, t, aux);
+    apply_chain(S, o, r);
+    return prim_t(obj_type(o.head), o.f, r, tMin, tMax, t, aux);
 }
 
 /* ConstantMedium::hit Volumes.cuh:26-49 (ray already in the medium's frame) */
@@ -273,70 +295,87 @@ __device__ __forceinline__ bool medium_t(const DScene& S, const DObj& o, const D
     return true;
 }
 
-/* Aabb::hit Aabb.cuh:31-44 against a 32-byte node */
-__device__ __forceinline__ bool node_hit(const rt_bvh_node& n, const DRay& r, float tMin, float tMax)
+/* ------------------------------------------------------------ BVH traversal ---- */
+/* Slab test of one child box with the reciprocal direction.  Culling never decides a result (the
+ * primitives do, with the reference's arithmetic), it only has to be conservative: the far bound is
+ * widened by a few ulps so that rounding in (b - o) * (1/d) cannot drop a box the exact test keeps
+ * (host-side boxes are padded as well, lower.cpp pad_box). */
+__device__ __forceinline__ bool slab(const float* bmin, const float* bmax, V3 o, V3 id, float tMin, float tMax, float& tnear)
 {
-    float ta = (n.bmin[0] - r.o.x) / r.d.x, tb = (n.bmax[0] - r.o.x) / r.d.x;
-    tMin = fmaxf(fminf(ta, tb), tMin); tMax = fminf(fmaxf(ta, tb), tMax);
-    if (tMax <= tMin) return false;
-    ta = (n.bmin[1] - r.o.y) / r.d.y; tb = (n.bmax[1] - r.o.y) / r.d.y;
-    tMin = fmaxf(fminf(ta, tb), tMin); tMax = fminf(fmaxf(ta, tb), tMax);
-    if (tMax <= tMin) return false;
-    ta = (n.bmin[2] - r.o.z) / r.d.z; tb = (n.bmax[2] - r.o.z) / r.d.z;
-    tMin = fmaxf(fminf(ta, tb), tMin); tMax = fminf(fmaxf(ta, tb), tMax);
-    return !(tMax <= tMin);
+    float x0 = (bmin[0] - o.x) * id.x, x1 = (bmax[0] - o.x) * id.x;
+    float y0 = (bmin[1] - o.y) * id.y, y1 = (bmax[1] - o.y) * id.y;
+    float z0 = (bmin[2] - o.z) * id.z, z1 = (bmax[2] - o.z) * id.z;
+    float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tMin));
+    float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tMax));
+    tnear = tn;
+    return tn <= tf * 1.0000008f;
+}
+
+/* Closest hit over one BVH (while-while traversal): the inner loop walks interior nodes until this
+ * lane holds a leaf, then the leaf's primitives are tested; the per-lane stack lives in LDS,
+ * entry i at stack[i * RT_BLOCK].  Near child first, far child pushed, best.t shrinking. */
+__device__ __forceinline__ void bvh_closest(const DScene& S, int gi, int root, const DRay& r, float tMin,
+                                            HitLite& best, int* stack)
+{
+    const V3 id = mk(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
+    int sp = 0;
+    int ref = root;
+    while (true) {
+        while (ref >= 0) {
+            const float4* np = reinterpret_cast<const float4*>(S.nodes + ref);
+            const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+            const float lmin[3] = {q0.x, q0.y, q0.z}, lmax[3] = {q0.w, q1.x, q1.y};
+            const float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
+            const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+            float tl, tr;
+            const bool hl = slab(lmin, lmax, r.o, id, tMin, best.t, tl);
+            const bool hr = slab(rmin, rmax, r.o, id, tMin, best.t, tr);
+            if (hl & hr) {
+                const bool lfirst = tl <= tr;
+                stack[sp * RT_BLOCK] = lfirst ? right : left;
+                ++sp;
+                ref = lfirst ? left : right;
+            } else if (hl | hr) {
+                ref = hl ? left : right;
+            } else {
+                ref = RT_REF_NONE;
+                if (sp > 0) { --sp; ref = stack[sp * RT_BLOCK]; }
+            }
+        }
+        if (ref == RT_REF_NONE) break;
+        const int first = (~ref) >> 4, count = ((~ref) & 15) + 1;
+        for (int i = 0; i < count; ++i) {
+            const DObj& lf = S.leafs[first + i];
+            float t; int aux;
+            bool h;
+            if (obj_op_count(lf.head) == 0) h = prim_t(obj_type(lf.head), lf.f, r, tMin, best.t, t, aux);
+            else h = leaf_t(S, S.objs[lf.prim_id], r, tMin, best.t, t, aux);     /* wrapped leaf: full row */
+            if (h) { best.t = t; best.obj = lf.prim_id; best.grp = gi; best.aux = aux; }
+        }
+        ref = RT_REF_NONE;
+        if (sp > 0) { --sp; ref = stack[sp * RT_BLOCK]; }
+        if (ref == RT_REF_NONE) break;
+    }
 }
 
 /* ------------------------------------------------------------ closest hit ---- */
-/* `stack` is this lane's column of the block's LDS stack: entry i at stack[i*RT_BLOCK]. */
 template <bool HAS_BVH>
 __device__ __forceinline__ void group_closest(const DScene& S, int gi, const DObj& g, DRay r, float tMin,
                                               HitLite& best, const PathRng* rng, uint32_t bounce, int* stack)
 {
-    apply_chain(S, g.op_begin, g.op_count, r);
-    if (HAS_BVH && g.bvh_root >= 0) {
-        int sp = 0;
-        int node = g.bvh_root;
-        while (true) {
-            const rt_bvh_node n = S.nodes[node];
-            bool descend = false;
-            if (node_hit(n, r, tMin, best.t)) {
-                if (n.count) {
-                    for (uint32_t i = 0; i < n.count; ++i) {
-                        int oi = S.items[n.left_first + i];
-                        float t; int aux;
-                        if (leaf_t(S, S.objs[oi], r, tMin, best.t, t, aux)) { best.t = t; best.obj = oi; best.grp = gi; best.aux = aux; }
-                    }
-                } else {
-                    /* nearer child first (by box centre along the ray), other one on the stack */
-                    const rt_bvh_node l = S.nodes[n.left_first], rr = S.nodes[n.left_first + 1];
-                    float dl = (0.5f * (l.bmin[0] + l.bmax[0]) - r.o.x) * r.d.x + (0.5f * (l.bmin[1] + l.bmax[1]) - r.o.y) * r.d.y +
-                               (0.5f * (l.bmin[2] + l.bmax[2]) - r.o.z) * r.d.z;
-                    float dr = (0.5f * (rr.bmin[0] + rr.bmax[0]) - r.o.x) * r.d.x + (0.5f * (rr.bmin[1] + rr.bmax[1]) - r.o.y) * r.d.y +
-                               (0.5f * (rr.bmin[2] + rr.bmax[2]) - r.o.z) * r.d.z;
-                    int near = dl <= dr ? (int)n.left_first : (int)n.left_first + 1;
-                    int far = dl <= dr ? (int)n.left_first + 1 : (int)n.left_first;
-                    if (sp < RT_STACK_DEPTH) { stack[sp * RT_BLOCK] = far; ++sp; }
-                    node = near;
-                    descend = true;
-                }
-            }
-            if (!descend) {
-                if (sp == 0) break;
-                --sp;
-                node = stack[sp * RT_BLOCK];
-            }
-        }
+    apply_chain(S, g, r);
+    if (HAS_BVH && (obj_flags(g.head) & RT_DOBJ_HAS_BVH)) {
+        bvh_closest(S, gi, g.bvh_root, r, tMin, best, stack);
         return;
     }
     for (int i = 0; i < g.child_count; ++i) {
         int oi = g.child_begin + i;
         const DObj& o = S.objs[oi];
         float t; int aux;
-        if (o.type == RT_OBJ_MEDIUM) {
+        if (obj_type(o.head) == RT_OBJ_MEDIUM) {
             if (rng) {
                 DRay rm = r;
-                apply_chain(S, o.op_begin, o.op_count, rm);
+                apply_chain(S, o, rm);
                 if (medium_t(S, o, rm, tMin, best.t, *rng, bounce, t)) { best.t = t; best.obj = oi; best.grp = gi; best.aux = 0; }
             }
         } else if (leaf_t(S, o, r, tMin, best.t, t, aux)) { best.t = t; best.obj = oi; best.grp = gi; best.aux = aux; }
@@ -350,100 +389,103 @@ __device__ __forceinline__ HitLite closest_hit(const DScene& S, const DRay& r, f
 {
     HitLite best = {tMax, -1, -1, 0};
     const DObj& w = S.objs[S.world];
-    if (HAS_BVH && w.bvh_root >= 0) {
+    if (HAS_BVH && (obj_flags(w.head) & RT_DOBJ_HAS_BVH)) {
         group_closest<HAS_BVH>(S, -1, w, r, tMin, best, rng, bounce, stack);
         return best;
     }
     for (int i = 0; i < w.child_count; ++i) {
         int oi = w.child_begin + i;
         const DObj& o = S.objs[oi];
+        const int ty = obj_type(o.head);
         float t; int aux;
-        if (o.type == RT_OBJ_GROUP) {
+        if (ty == RT_OBJ_GROUP) {
             group_closest<HAS_BVH>(S, oi, o, r, tMin, best, rng, bounce, stack);
-        } else if (o.type == RT_OBJ_MEDIUM) {
+        } else if (ty == RT_OBJ_MEDIUM) {
             if (rng) {
                 DRay rm = r;
-                apply_chain(S, o.op_begin, o.op_count, rm);
+                apply_chain(S, o, rm);
                 if (medium_t(S, o, rm, tMin, best.t, *rng, bounce, t)) { best.t = t; best.obj = oi; best.grp = -1; best.aux = 0; }
             }
-        } else if (leaf_t(S, o, r, tMin, best.t, t, aux)) { best.t = t; best.obj = oi; best.grp = -1; best.aux = aux; }
+        } else {
+            const bool h_ = leaf_t(S, o, r, tMin, best.t, t, aux);
+            if (h_) { best.t = t; best.obj = oi; best.grp = -1; best.aux = aux; }
+        }
     }
     return best;
 }
 
 /* --------------------------------------------------- rebuild the record ---- */
 /* combined wrapper chain of the winner: the group's ops then the leaf's, outermost first */
-struct Chain { int gb, gc, lb, lc; };
-__device__ __forceinline__ const rt_xform_op& chain_op(const DScene& S, const Chain& c, int k)
+__device__ __forceinline__ OpV chain_op(const DScene& S, const DObj& grp, int gc, const DObj& o, int k)
 {
-    return S.ops[k < c.gc ? c.gb + k : c.lb + (k - c.gc)];
+    return k < gc ? obj_op(S, grp, k) : obj_op(S, o, k - gc);
 }
 
+template <bool WANT_UV>
 __device__ __forceinline__ void rebuild(const DScene& S, const DRay& world_ray, const HitLite& hl, float tMin, HitRec& h)
 {
     const DObj& o = S.objs[hl.obj];
-    Chain c = {0, 0, o.op_begin, o.op_count};
-    if (hl.grp >= 0) { c.gb = S.objs[hl.grp].op_begin; c.gc = S.objs[hl.grp].op_count; }
-    const int n = c.gc + c.lc;
+    const DObj& grp = S.objs[hl.grp >= 0 ? hl.grp : hl.obj];
+    const int gc = hl.grp >= 0 ? obj_op_count(grp.head) : 0;
+    const int n = gc + obj_op_count(o.head);
     DRay r = world_ray;
-    for (int k = 0; k < n; ++k) apply_op(chain_op(S, c, k), r);
+    for (int k = 0; k < n; ++k) { const OpV op = chain_op(S, grp, gc, o, k); apply_op(op.type, op.a, op.b, op.c, r); }
 
     const float t = hl.t;
     h.t = t; h.u = 0.f; h.v = 0.f; h.front = 0;
     h.material = o.material;
     h.prim_id = o.prim_id;
-    switch (o.type) {
-    case RT_OBJ_SPHERE: {
+    /* u,v feed image textures only (Texture.cuh:49-61); the render kernel skips them otherwise */
+    const bool want_uv = WANT_UV || (S.mats[o.material].pad != 0);
+    const int ty = obj_type(o.head);
+    if (ty >= RT_OBJ_RECT_XY && ty <= RT_OBJ_BOX) {
+        /* the three rect kinds and the six box faces (Box.cuh:24-36) through one body */
+        const float* f = o.f;
+        const bool box = ty == RT_OBJ_BOX;
+        const int face = hl.aux;      /* the face whose test produced t in the search */
+        const int KA = box ? 2 - (face >> 1) : (int)RT_OBJ_RECT_YZ - ty;
+        const float a0 = box ? (KA == 0 ? f[1] : f[0]) : f[0];
+        const float a1 = box ? (KA == 0 ? f[4] : f[3]) : f[1];
+        const float b0 = box ? (KA == 2 ? f[1] : f[2]) : f[2];
+        const float b1 = box ? (KA == 2 ? f[4] : f[5]) : f[3];
+        rect_rec<WANT_UV>(KA, a0, a1, b0, b1, r, t, want_uv, h);
+        if (box && (face & 1)) h.front = !h.front;          /* FlipNormals, Surface.cuh:24 */
+    } else if (ty == RT_OBJ_SPHERE) {
         V3 centre = ld3(o.f);
         h.p = at(r, t);
         h.n = (h.p - centre) / o.f[3];
-        V3 q = (h.p - centre) / o.f[3];
-        float phi = atan2f(q.z, q.x);                       /* getSphereUV Sphere.cuh:64-70 */
-        float theta = asinf(q.y);
-        h.u = (float)(1 - (phi + RT_PI_D) / (2 * RT_PI_D));
-        h.v = (float)((theta + RT_PI_D / 2) / RT_PI_D);
-    } break;
-    case RT_OBJ_MOVING_SPHERE: {
+        if (want_uv) {
+            V3 q = (h.p - centre) / o.f[3];
+            float phi = atan2f(q.z, q.x);                       /* getSphereUV Sphere.cuh:64-70 */
+            float theta = asinf(q.y);
+            h.u = (float)(1 - (phi + RT_PI_D) / (2 * RT_PI_D));
+            h.v = (float)((theta + RT_PI_D / 2) / RT_PI_D);
+        }
+    } else if (ty == RT_OBJ_MOVING_SPHERE) {
         V3 centre = moving_centre(o.f, r.time);
         h.p = at(r, t);
         h.n = (h.p - centre) / o.f[8];
-    } break;
-    case RT_OBJ_RECT_XY: rect_rec<2>(o.f[0], o.f[1], o.f[2], o.f[3], r, t, h); break;
-    case RT_OBJ_RECT_XZ: rect_rec<1>(o.f[0], o.f[1], o.f[2], o.f[3], r, t, h); break;
-    case RT_OBJ_RECT_YZ: rect_rec<0>(o.f[0], o.f[1], o.f[2], o.f[3], r, t, h); break;
-    case RT_OBJ_BOX: {
-        const float* f = o.f;
-        const int face = hl.aux;      /* the face whose test produced t in the search */
-        switch (face) {
-        case 0: case 1: rect_rec<2>(f[0], f[3], f[1], f[4], r, t, h); break;
-        case 2: case 3: rect_rec<1>(f[0], f[3], f[2], f[5], r, t, h); break;
-        default:        rect_rec<0>(f[1], f[4], f[2], f[5], r, t, h); break;
-        }
-        if (face & 1) h.front = !h.front;                   /* FlipNormals, Surface.cuh:24 */
-    } break;
-    case RT_OBJ_TRIANGLE: {
+    } else if (ty == RT_OBJ_TRIANGLE) {
         V3 normal = ld3(o.f + 9);
         h.p = at(r, t);
         h.n = dot(normal, r.d) > 0 ? -normal : normal;      /* Triangle.cuh:38-41 */
-    } break;
-    default: /* RT_OBJ_MEDIUM, Volumes.cuh:44-46 */
+    } else { /* RT_OBJ_MEDIUM, Volumes.cuh:44-46 */
         h.p = at(r, t);
         h.n = mk(1.f, 0.f, 0.f);
         h.front = 1;
-        break;
     }
-    if (o.flags & RT_OBJ_FLAG_FLIP) h.front = !h.front;
+    if (obj_flags(o.head) & RT_OBJ_FLAG_FLIP) h.front = !h.front;
 
     /* unwind the wrappers, innermost first (Transform.cuh:24, :101-108) */
     for (int k = n - 1; k >= 0; --k) {
-        const rt_xform_op& op = chain_op(S, c, k);
+        const OpV op = chain_op(S, grp, gc, o, k);
         if (op.type == RT_OP_TRANSLATE) {
             h.p = h.p + mk(op.a, op.b, op.c);
         } else {
             /* direction of the ray as this RotateY saw it after rotating: ops 0..k applied */
             V3 d = world_ray.d;
             for (int j = 0; j <= k; ++j) {
-                const rt_xform_op& oj = chain_op(S, c, j);
+                const OpV oj = chain_op(S, grp, gc, o, j);
                 if (oj.type == RT_OP_ROTATE_Y) {
                     float dx = oj.b * d.x - oj.a * d.z, dz = oj.a * d.x + oj.b * d.z;
                     d.x = dx; d.z = dz;
@@ -496,6 +538,64 @@ __device__ __forceinline__ V3 random_in_unit_sphere(const PathRng& g, uint32_t b
     } while (dot(p, p) >= 1.f);
     return p;
 }
+/* The same sample, drawn by the whole wave.  Each lane that needs a unit-ball point (`need`) owns the
+ * candidate sequence k = 0,1,2,... of its own (pixel, sample, bounce); a rejection loop run per lane keeps
+ * the wave going for its unluckiest lane (about 7 rounds for a mean of 1.9 candidates) with most lanes idle.
+ * Here, once at most half the lanes still need a point, the idle lanes evaluate further candidates of the
+ * needy ones: with n lanes in need, lane l evaluates candidate k_owner + l / n of the (l mod n)-th needy lane,
+ * and every owner takes the first accepted one, so the result is bit for bit what its own loop would give.
+ * Must be called by all 64 lanes of the wave together.  `slots` = 64 ints of LDS private to this wave. */
+__device__ __forceinline__ V3 random_in_unit_sphere_wave(const PathRng& g, uint32_t bounce, bool need, int* slots)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    V3 res = mk(0.f, 0.f, 0.f);
+    uint32_t k = 0;
+    unsigned long long mask = __ballot(need);
+    while (mask) {
+        const int n = __popcll(mask);
+        if (n > 32) {
+            if (need) {
+                rt_u32x4 w = rng_block(g, RT_RNG_SPHERE, bounce, k++);
+                V3 p = 2.f * mk(rt_u32_to_uniform(w.x), rt_u32_to_uniform(w.y), rt_u32_to_uniform(w.z)) - mk(1.f, 1.f, 1.f);
+                if (!(dot(p, p) >= 1.f)) { res = p; need = false; }
+            }
+        } else {
+            int c = 64 / n;
+            c = c > 8 ? 8 : c;
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if (need) slots[rank] = lane;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int j = lane / n, r = lane - j * n;
+            const bool helper = j < c;
+            const int owner = helper ? slots[r] : lane;
+            const uint32_t o_pixel = (uint32_t)__builtin_amdgcn_ds_bpermute(owner << 2, (int)g.pixel);
+            const uint32_t o_sample = (uint32_t)__builtin_amdgcn_ds_bpermute(owner << 2, (int)g.sample);
+            const uint32_t o_ctr = (uint32_t)__builtin_amdgcn_ds_bpermute(owner << 2, (int)((RT_RNG_SPHERE << 24) | bounce));
+            const uint32_t o_k = (uint32_t)__builtin_amdgcn_ds_bpermute(owner << 2, (int)k);
+            rt_u32x4 w = rt_philox4x32_10(o_k + (uint32_t)j, o_ctr, o_pixel, o_sample, g.k0, g.k1);
+            V3 p = 2.f * mk(rt_u32_to_uniform(w.x), rt_u32_to_uniform(w.y), rt_u32_to_uniform(w.z)) - mk(1.f, 1.f, 1.f);
+            const unsigned long long acc = __ballot(helper && !(dot(p, p) >= 1.f));
+            int src = lane;
+            bool found = false;
+            for (int jj = c - 1; jj >= 0; --jj) {          /* c is wave-uniform; lowest jj wins */
+                const int h = rank + jj * n;
+                if (need && ((acc >> h) & 1ull)) { src = h; found = true; }
+            }
+            const float px = __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(p.x)));
+            const float py = __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(p.y)));
+            const float pz = __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(p.z)));
+            if (need) {
+                if (found) { res = mk(px, py, pz); need = false; }
+                else k += (uint32_t)c;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        mask = __ballot(need);
+    }
+    return res;
+}
 __device__ __forceinline__ V3 reflect(V3 v, V3 n) { return v - (2.f * dot(v, n)) * n; }   /* Material.cuh:42 */
 __device__ __forceinline__ float schlick(float cosine, float refIdx)              /* Material.cuh:12-17 */
 {
@@ -516,8 +616,10 @@ __device__ __forceinline__ bool refract(V3 v, V3 n, float niOverNt, V3& refracte
 }
 
 /* Material::scatter + emitted (Material.cuh:51-144). Returns false when the path ends. */
+/* `ball` = randomInUnitSphere() for this bounce, drawn by the caller (random_in_unit_sphere_wave) when the
+ * material is Lambert, Metal or Isotropic */
 __device__ __forceinline__ bool scatter(const DScene& S, const DRay& in, const HitRec& rec, const PathRng& g,
-                                        uint32_t bounce, V3& attenuation, DRay& out, V3& emitted)
+                                        uint32_t bounce, V3 ball, V3& attenuation, DRay& out, V3& emitted)
 {
     const rt_material m = S.mats[rec.material];
     emitted = mk(0.f, 0.f, 0.f);
@@ -526,14 +628,14 @@ __device__ __forceinline__ bool scatter(const DScene& S, const DRay& in, const H
     out.time = in.time;
     switch (m.type) {
     case RT_MAT_LAMBERT: {
-        V3 target = rec.p + rec.n + random_in_unit_sphere(g, bounce);
+        V3 target = rec.p + rec.n + ball;
         out.d = target - rec.p;
         attenuation = texture_value(S, m.texture, rec.u, rec.v, rec.p);
         return true;
     }
     case RT_MAT_METAL: {
         V3 reflected = reflect(unit(in.d), rec.n);
-        out.d = reflected + m.param * random_in_unit_sphere(g, bounce);
+        out.d = reflected + m.param * ball;
         attenuation = texture_value(S, m.texture, 0, 0, rec.p);
         return dot(out.d, rec.n) > 0.f;
     }
@@ -563,7 +665,7 @@ __device__ __forceinline__ bool scatter(const DScene& S, const DRay& in, const H
         emitted = texture_value(S, m.texture, rec.u, rec.v, rec.p);
         return false;
     default: /* Isotropic: time resets to 0 (Material.cuh:140) */
-        out.d = random_in_unit_sphere(g, bounce);
+        out.d = ball;
         out.time = 0.f;
         attenuation = texture_value(S, m.texture, rec.u, rec.v, rec.p);
         return true;

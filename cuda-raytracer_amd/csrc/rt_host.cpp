@@ -107,9 +107,14 @@ void rt_pack_objects(const rt_flat_scene* s, DObj* out)
         const rt_object& o = s->objects[i];
         DObj d;
         std::memset(&d, 0, sizeof d);
-        d.type = o.type; d.material = o.material; d.op_begin = o.op_begin; d.op_count = o.op_count;
-        d.child_begin = o.child_begin; d.child_count = o.child_count; d.bvh_root = o.bvh_root;
-        d.medium_slot = o.medium_slot; d.prim_id = o.prim_id; d.flags = o.flags;
+        uint32_t t0 = o.op_count > 0 ? (uint32_t)s->ops[o.op_begin].type : 0u;
+        uint32_t t1 = o.op_count > 1 ? (uint32_t)s->ops[o.op_begin + 1].type : 0u;
+        d.head = (uint32_t)o.type | ((o.flags & 0x7fu) << 8) | ((uint32_t)o.op_count << 16) | (t0 << 24) | (t1 << 28);
+        d.material = o.material; d.prim_id = o.prim_id;
+        d.op_begin = o.op_begin; d.child_begin = o.child_begin; d.child_count = o.child_count;
+        d.bvh_root = RT_REF_NONE; d.medium_slot = o.medium_slot;
+        if (o.op_count > 0) { const rt_xform_op& p = s->ops[o.op_begin];     d.op0[0] = p.a; d.op0[1] = p.b; d.op0[2] = p.c; }
+        if (o.op_count > 1) { const rt_xform_op& p = s->ops[o.op_begin + 1]; d.op1[0] = p.a; d.op1[1] = p.b; d.op1[2] = p.c; }
         for (int k = 0; k < 10; ++k) d.f[k] = o.f[k];
         if (o.type == RT_OBJ_TRIANGLE) {
             const float* f = o.f;
@@ -124,6 +129,61 @@ void rt_pack_objects(const rt_flat_scene* s, DObj* out)
         }
         out[i] = d;
     }
+}
+
+bool rt_pack_bvh(const rt_flat_scene* s, std::vector<DObj>& objs, std::vector<DNode>& nodes,
+                 std::vector<DObj>& leafs, int* depth, std::string& why)
+{
+    nodes.clear();
+    leafs.assign((size_t)s->n_bvh_items, DObj());
+    for (int j = 0; j < s->n_bvh_items; ++j) {
+        leafs[j] = objs[(size_t)s->bvh_items[j]];
+        leafs[j].prim_id = s->bvh_items[j];           /* object index: rebuild and reporting go through objs */
+    }
+    int deepest = 0;
+    bool ok = true;
+    auto child_ref = [&](uint32_t ni, std::vector<std::pair<uint32_t, int>>& todo) -> int32_t {
+        const rt_bvh_node& c = s->bvh_nodes[ni];
+        if (c.count) {
+            if (c.count > RT_MAX_LEAF) { ok = false; return RT_REF_NONE; }
+            return ~(int32_t)((c.left_first << 4) | (c.count - 1));
+        }
+        int32_t id = (int32_t)nodes.size();
+        nodes.push_back(DNode());
+        todo.push_back({ni, id});
+        return id;
+    };
+    for (int gi = 0; gi < s->n_objects; ++gi) {
+        const rt_object& g = s->objects[gi];
+        if (g.type != RT_OBJ_GROUP || g.bvh_root < 0) continue;
+        std::vector<std::pair<uint32_t, int>> todo;   /* (ABI interior node, DNode index) */
+        std::vector<int> level;                        /* depth of each DNode of this BVH, by (index - base) */
+        const int base = (int)nodes.size();
+        int32_t root = child_ref((uint32_t)g.bvh_root, todo);
+        if (!ok) { why = "BVH leaf larger than 16 items"; return false; }
+        level.assign(nodes.size() - base, 1);
+        while (!todo.empty()) {
+            std::pair<uint32_t, int> e = todo.back();
+            todo.pop_back();
+            const rt_bvh_node& n = s->bvh_nodes[e.first];
+            const rt_bvh_node& l = s->bvh_nodes[n.left_first];
+            const rt_bvh_node& r = s->bvh_nodes[n.left_first + 1];
+            size_t before = nodes.size();
+            int32_t lr = child_ref(n.left_first, todo);
+            int32_t rr = child_ref(n.left_first + 1, todo);
+            if (!ok) { why = "BVH leaf larger than 16 items"; return false; }
+            DNode& d = nodes[(size_t)e.second];
+            for (int k = 0; k < 3; ++k) { d.lmin[k] = l.bmin[k]; d.lmax[k] = l.bmax[k]; d.rmin[k] = r.bmin[k]; d.rmax[k] = r.bmax[k]; }
+            d.left = lr; d.right = rr; d.pad[0] = d.pad[1] = 0;
+            int lv = level[(size_t)(e.second - base)];
+            if (lv > deepest) deepest = lv;
+            for (size_t q = before; q < nodes.size(); ++q) level.push_back(lv + 1);
+        }
+        objs[(size_t)gi].bvh_root = root;
+        objs[(size_t)gi].head |= RT_DOBJ_HAS_BVH << 8;
+    }
+    if (depth) *depth = deepest;
+    return true;
 }
 
 extern "C" int rt_quantise_rgb8(const float* rgb, int width, int height, uint8_t* out)

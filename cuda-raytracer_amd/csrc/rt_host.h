@@ -7,16 +7,39 @@
 #include <string>
 #include "../../include/rt_scene.h"
 
-/* device row of the object table: 128 bytes, two cache-line halves */
+/* Device row of the object table: 128 bytes = two 64-byte halves.
+ * The first half is a self-contained "bare" primitive (type, material, id, parameters): one
+ * s_load_dwordx16 when the row is wave-uniform (list scan), one cache line per lane in a BVH leaf.
+ * The second half holds what only wrapped objects, groups and media need: the first two wrapper ops
+ * inline (Translate(RotateY(x)) is the reference's idiom, main.cu:294-295), the rest of the chain by
+ * index, and the child / BVH / medium links. */
 struct alignas(16) DObj {
-    int32_t  type, material, op_begin, op_count;
-    int32_t  child_begin, child_count, bvh_root, medium_slot;
-    int32_t  prim_id;
-    uint32_t flags;
-    int32_t  pad0, pad1;
-    float    f[16];   /* rt_object::f; triangles add the unit normal f[9..11] and plane offset f[12] */
-    float    pad2[4];
+    uint32_t head;        /* type | flags<<8 | op_count<<16 | op0 type<<24 | op1 type<<28 */
+    int32_t  material;
+    int32_t  prim_id;     /* in the BVH leaf table (DScene::leafs): the object's index instead */
+    float    f[13];       /* rt_object::f; triangles add the unit normal f[9..11] and plane offset f[12] */
+    float    op0[3];      /* outermost wrapper: Translate offset, or RotateY (sin, cos, -) */
+    float    op1[3];
+    int32_t  op_begin;    /* chains longer than two continue in the ops table at op_begin + 2 */
+    int32_t  child_begin, child_count;
+    int32_t  bvh_root;    /* child reference of the group's BVH root (valid when RT_DOBJ_HAS_BVH) */
+    int32_t  medium_slot;
+    int32_t  pad[5];
 };
+#define RT_DOBJ_HAS_BVH 0x80u     /* in the flags byte of head */
+
+/* Device BVH node, 64 bytes = one cache line: the boxes of BOTH children, so that a visit decides
+ * which children to enter, and in which order, from one line (the 32-byte ABI node needs its own
+ * line plus both children's to do the same).  A child reference >= 0 is another DNode; < 0 is a leaf:
+ * ~ref = first_item << 4 | (count - 1), items being rows of the leaf table in BVH order. */
+struct alignas(16) DNode {
+    float   lmin[3], lmax[3], rmin[3], rmax[3];
+    int32_t left, right;
+    int32_t pad[2];
+};
+#define RT_REF_NONE ((int32_t)0x80000000)
+#define RT_MAX_LEAF 16
+#define RT_MAX_STACK 64
 
 void rt_set_error(const std::string& msg);
 
@@ -26,7 +49,14 @@ void rt_set_error(const std::string& msg);
 bool rt_validate_scene(const rt_flat_scene* s, std::string& why, int* bvh_depth);
 
 /* rt_object -> DObj; precomputes each triangle's unit normal and plane offset with the
- * expressions of Triangle.cuh:23-24 */
+ * expressions of Triangle.cuh:23-24.  bvh_root is left for rt_pack_bvh to fill. */
 void rt_pack_objects(const rt_flat_scene* s, DObj* out);
+
+/* 32-byte ABI nodes -> DNodes + the leaf table (first halves of the item objects, in item order);
+ * sets bvh_root / RT_DOBJ_HAS_BVH of every group that has a BVH.  Returns false (why) for a leaf
+ * larger than RT_MAX_LEAF.  depth receives the deepest DNode chain (= traversal stack entries). */
+#include <vector>
+bool rt_pack_bvh(const rt_flat_scene* s, std::vector<DObj>& objs, std::vector<DNode>& nodes,
+                 std::vector<DObj>& leafs_full, int* depth, std::string& why);
 
 #endif

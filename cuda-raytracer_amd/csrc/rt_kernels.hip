@@ -20,8 +20,21 @@
 #include "rt_device.h"
 #include "rt_host.h"
 
+#define RT_N_COUNTERS 16        /* rays, samples, then diagnostic slots */
 #ifndef RT_RENDER_WAVES
 #define RT_RENDER_WAVES 4      /* waves per SIMD the render kernel is compiled for (<=128 VGPRs) */
+#endif
+
+/* Diagnostic build only (-DRT_STAMPS, tools/diag): shader-clock time of each section of the render
+ * loop, summed per wave into counters[4 + section].  No stamp executes in the shipped library. */
+#ifdef RT_STAMPS
+#define RT_STAMP_DECL unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}; unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#define RT_STAMP(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); st_acc[i] += now_ - st_last; st_last = now_; }
+#define RT_STAMP_FLUSH if ((threadIdx.x & 63) == 0) { for (int q_ = 0; q_ < 6; ++q_) atomicAdd(&counters[4 + q_], st_acc[q_]); }
+#else
+#define RT_STAMP_DECL
+#define RT_STAMP(i)
+#define RT_STAMP_FLUSH
 #endif
 
 /* ------------------------------------------------------------------ kernels -- */
@@ -29,7 +42,7 @@ template <bool HAS_BVH>
 __global__ __launch_bounds__(RT_BLOCK) void trace_rays_kernel(DScene S, int n, const float* __restrict__ rays,
                                                                float tmin, float tmax, rt_hit_record* __restrict__ out)
 {
-    __shared__ int stack_mem[HAS_BVH ? RT_STACK_DEPTH * RT_BLOCK : 1];
+    extern __shared__ int stack_mem[];                 /* HAS_BVH: stack_depth x RT_BLOCK ints */
     int* stack = stack_mem + (HAS_BVH ? threadIdx.x : 0);
     int i = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -44,7 +57,7 @@ __global__ __launch_bounds__(RT_BLOCK) void trace_rays_kernel(DScene S, int n, c
     o.prim = -1;
     if (hl.obj >= 0) {
         HitRec h;
-        rebuild(S, r, hl, tmin, h);
+        rebuild<true>(S, r, hl, tmin, h);
         o.hit = 1; o.prim = h.prim_id; o.t = h.t; o.u = h.u; o.v = h.v;
         o.p[0] = h.p.x; o.p[1] = h.p.y; o.p[2] = h.p.z;
         o.n[0] = h.n.x; o.n[1] = h.n.y; o.n[2] = h.n.z;
@@ -75,7 +88,7 @@ template <bool HAS_BVH>
 __global__ __launch_bounds__(RT_BLOCK) void trace_primary_kernel(DScene S, int W, int H, float s_off, float t_off,
                                                                   int32_t* __restrict__ prim, float* __restrict__ t_out)
 {
-    __shared__ int stack_mem[HAS_BVH ? RT_STACK_DEPTH * RT_BLOCK : 1];
+    extern __shared__ int stack_mem[];
     int* stack = stack_mem + (HAS_BVH ? threadIdx.x : 0);
     int i, j;
     tile_pixel(W, xcd_tile(blockIdx.x, gridDim.x), threadIdx.x, i, j);
@@ -95,8 +108,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_RENDER_WAVES) void render_kernel(DScen
                                                            float* __restrict__ accum,
                                                            unsigned long long* __restrict__ counters)
 {
-    __shared__ int stack_mem[HAS_BVH ? RT_STACK_DEPTH * RT_BLOCK : 1];
-    int* stack = stack_mem + (HAS_BVH ? threadIdx.x : 0);
+    extern __shared__ int stack_mem[];                 /* RT_BLOCK ints, then HAS_BVH: stack_depth x RT_BLOCK */
+    int* slots = stack_mem + (threadIdx.x & ~63u);     /* 64 ints per wave for the wave-wide ball draw */
+    int* stack = stack_mem + RT_BLOCK + (HAS_BVH ? threadIdx.x : 0);
     int i, j;
     tile_pixel(W, xcd_tile(blockIdx.x, gridDim.x), threadIdx.x, i, j);
     const bool valid = i < W && j < H;
@@ -113,7 +127,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_RENDER_WAVES) void render_kernel(DScen
     PathRng g;
     rng_start(g, k0, k1, pixel, 0u);
 
+    RT_STAMP_DECL
     while (true) {
+        RT_STAMP(5)
         if (!alive && s < s_end) {
             /* main.cu:185-188: jittered pixel position, camera ray, fresh path */
             rng_start(g, k0, k1, pixel, s);
@@ -127,19 +143,37 @@ __global__ __launch_bounds__(RT_BLOCK, RT_RENDER_WAVES) void render_kernel(DScen
             alive = true;
             ++s;
         }
+        RT_STAMP(0)
         if (__ballot(alive) == 0ull) break;
+        /* one iteration of colour() / colourUnlit(), main.cu:53-70 / :77-98, for every live lane.  The
+         * body is kept flat (flags, not nested branches) because the unit-ball draw in the middle is
+         * made by all 64 lanes together. */
+        HitLite hl = {FLT_MAX, -1, -1, 0};
         if (alive) {
-            /* one iteration of colour() / colourUnlit(), main.cu:53-70 / :77-98 */
-            HitLite hl = closest_hit<HAS_BVH>(S, ray, .001f, FLT_MAX, &g, (uint32_t)depth, stack);
+            hl = closest_hit<HAS_BVH>(S, ray, .001f, FLT_MAX, &g, (uint32_t)depth, stack);
             ++n_rays;
+        }
+        RT_STAMP(1)
+        const bool hit = alive && hl.obj >= 0;
+        HitRec rec;
+        rec.t = 0.f; rec.u = 0.f; rec.v = 0.f; rec.p = mk(0.f, 0.f, 0.f); rec.n = mk(0.f, 0.f, 0.f);
+        rec.material = 0; rec.prim_id = -1; rec.front = 0;
+        int mtype = RT_MAT_LIGHT;
+        if (hit) {
+            rebuild<false>(S, ray, hl, .001f, rec);
+            mtype = S.mats[rec.material].type;
+        }
+        RT_STAMP(2)
+        const bool need_ball = hit && (mtype == RT_MAT_LAMBERT || mtype == RT_MAT_METAL || mtype == RT_MAT_ISOTROPIC);
+        const V3 ball = random_in_unit_sphere_wave(g, (uint32_t)depth, need_ball, slots);
+        RT_STAMP(3)
+        if (alive) {
             V3 result;
             bool done;
-            if (hl.obj >= 0) {
-                HitRec rec;
-                rebuild(S, ray, hl, .001f, rec);
+            if (hit) {
                 V3 attenuation, emitted;
                 DRay scattered;
-                if (scatter(S, ray, rec, g, (uint32_t)depth, attenuation, scattered, emitted)) {
+                if (scatter(S, ray, rec, g, (uint32_t)depth, ball, attenuation, scattered, emitted)) {
                     att = att * attenuation;
                     if (BG == RT_BG_BLACK) emi = emi + emitted * att;
                     ray = scattered;
@@ -170,6 +204,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_RENDER_WAVES) void render_kernel(DScen
             }
         }
     }
+    RT_STAMP(4)
+    RT_STAMP_FLUSH
     if (valid) {
         float* a = accum + 3 * (size_t)pixel;
         a[0] += sum.x; a[1] += sum.y; a[2] += sum.z;
@@ -211,9 +247,10 @@ struct rt_ctx {
     bool own_stream = false;
     bool have_scene = false;
     bool has_bvh = false;
+    int stack_depth = 0;      /* LDS stack entries per lane the uploaded BVHs need */
     DScene ds;
     void* d_objs = nullptr;  void* d_ops = nullptr;   void* d_mats = nullptr; void* d_texs = nullptr;
-    void* d_image = nullptr; void* d_nodes = nullptr; void* d_items = nullptr;
+    void* d_image = nullptr; void* d_nodes = nullptr; void* d_leafs = nullptr;
     unsigned long long* d_counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     /* render launches whose event pair has not been read back yet are timed lazily */
@@ -224,7 +261,7 @@ struct rt_ctx {
 
 static void free_scene(rt_ctx* c)
 {
-    void** ptrs[] = {&c->d_objs, &c->d_ops, &c->d_mats, &c->d_texs, &c->d_image, &c->d_nodes, &c->d_items};
+    void** ptrs[] = {&c->d_objs, &c->d_ops, &c->d_mats, &c->d_texs, &c->d_image, &c->d_nodes, &c->d_leafs};
     for (void** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
     c->have_scene = false;
 }
@@ -243,8 +280,8 @@ extern "C" int rt_ctx_create(int device, void* stream, rt_ctx** out)
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; rt_set_error("hipStreamCreate failed"); return RT_ERR_HIP; }
         c->own_stream = true;
     }
-    if (hipMalloc((void**)&c->d_counters, 2 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemsetAsync(c->d_counters, 0, 2 * sizeof(unsigned long long), c->stream) != hipSuccess) {
+    if (hipMalloc((void**)&c->d_counters, RT_N_COUNTERS * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemsetAsync(c->d_counters, 0, RT_N_COUNTERS * sizeof(unsigned long long), c->stream) != hipSuccess) {
         rt_ctx_destroy(c);
         rt_set_error("counter allocation failed");
         return RT_ERR_HIP;
@@ -280,36 +317,58 @@ extern "C" int rt_scene_upload(rt_ctx* c, const rt_flat_scene* s)
     std::string why;
     int bvh_depth = 0;
     if (!rt_validate_scene(s, why, &bvh_depth)) { rt_set_error("rt_scene_upload: invalid scene: " + why); return RT_ERR_ARG; }
-    if (bvh_depth > RT_STACK_DEPTH) { rt_set_error("rt_scene_upload: BVH deeper than the traversal stack"); return RT_ERR_UNSUPPORTED; }
+    std::vector<DObj> objs((size_t)s->n_objects);
+    rt_pack_objects(s, objs.data());
+    std::vector<DNode> nodes;
+    std::vector<DObj> leafs;
+    int stack_depth = 0;
+    if (!rt_pack_bvh(s, objs, nodes, leafs, &stack_depth, why)) { rt_set_error("rt_scene_upload: " + why); return RT_ERR_UNSUPPORTED; }
+    if (stack_depth > RT_MAX_STACK) { rt_set_error("rt_scene_upload: BVH deeper than the traversal stack (64)"); return RT_ERR_UNSUPPORTED; }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     free_scene(c);
 
-    std::vector<DObj> objs((size_t)s->n_objects);
-    rt_pack_objects(s, objs.data());
     int rc;
     if ((rc = upload(c, &c->d_objs, objs.data(), objs.size()))) return rc;
     if ((rc = upload(c, &c->d_ops, s->ops, (size_t)s->n_ops))) return rc;
-    if ((rc = upload(c, &c->d_mats, s->materials, (size_t)s->n_materials))) return rc;
+    /* device copy of the material table: pad = 1 when scatter()/emitted() read the record's u,v,
+     * i.e. an ImageTexture is reachable from the material's texture (Metal passes 0,0: Material.cuh:76) */
+    std::vector<rt_material> mats(s->materials, s->materials + s->n_materials);
+    for (rt_material& m : mats) {
+        m.pad = 0;
+        if (m.type == RT_MAT_GLASS || m.type == RT_MAT_METAL || m.texture < 0) continue;
+        std::vector<int> todo(1, m.texture);
+        for (size_t guard = 0; !todo.empty() && guard < 64; ++guard) {
+            const rt_texture& tx = s->textures[todo.back()];
+            todo.pop_back();
+            if (tx.type == RT_TEX_IMAGE) m.pad = 1;
+            else if (tx.type == RT_TEX_CHECKER) { todo.push_back(tx.even); todo.push_back(tx.odd); }
+        }
+        if (!todo.empty()) m.pad = 1;   /* very deep checker nest: be safe */
+    }
+    if ((rc = upload(c, &c->d_mats, mats.data(), mats.size()))) return rc;
     if ((rc = upload(c, &c->d_texs, s->textures, (size_t)s->n_textures))) return rc;
     if ((rc = upload(c, &c->d_image, s->image_bytes, (size_t)s->n_image_bytes))) return rc;
-    if ((rc = upload(c, &c->d_nodes, s->bvh_nodes, (size_t)s->n_bvh_nodes))) return rc;
-    if ((rc = upload(c, &c->d_items, s->bvh_items, (size_t)s->n_bvh_items))) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream)); /* objs is a local */
+    if ((rc = upload(c, &c->d_nodes, nodes.data(), nodes.size()))) return rc;
+    if ((rc = upload(c, &c->d_leafs, leafs.data(), leafs.size()))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream)); /* objs, nodes, leafs and mats are locals */
     c->ds.objs = (const DObj*)c->d_objs;
     c->ds.ops = (const rt_xform_op*)c->d_ops;
     c->ds.mats = (const rt_material*)c->d_mats;
     c->ds.texs = (const rt_texture*)c->d_texs;
     c->ds.image = (const uint8_t*)c->d_image;
-    c->ds.nodes = (const rt_bvh_node*)c->d_nodes;
-    c->ds.items = (const int32_t*)c->d_items;
+    c->ds.nodes = (const DNode*)c->d_nodes;
+    c->ds.leafs = (const DObj*)c->d_leafs;
     c->ds.world = s->world;
     c->ds.n_media = s->n_media;
     c->ds.cam = s->camera;
     c->has_bvh = s->n_bvh_nodes > 0;
+    c->stack_depth = stack_depth < 1 ? 1 : stack_depth;
     c->have_scene = true;
     return RT_OK;
 }
+
+static size_t stack_bytes(const rt_ctx* c) { return c->has_bvh ? (size_t)c->stack_depth * RT_BLOCK * sizeof(int) : 0; }
 
 static int need_scene(rt_ctx* c, const char* who)
 {
@@ -326,7 +385,7 @@ extern "C" int rt_trace_rays(rt_ctx* c, int n, const float* rays, float tmin, fl
     if (n == 0) return RT_OK;
     HIPCHK(hipSetDevice(c->device));
     dim3 grid((unsigned)((n + RT_BLOCK - 1) / RT_BLOCK));
-    if (c->has_bvh) trace_rays_kernel<true><<<grid, RT_BLOCK, 0, c->stream>>>(c->ds, n, rays, tmin, tmax, out);
+    if (c->has_bvh) trace_rays_kernel<true><<<grid, RT_BLOCK, stack_bytes(c), c->stream>>>(c->ds, n, rays, tmin, tmax, out);
     else trace_rays_kernel<false><<<grid, RT_BLOCK, 0, c->stream>>>(c->ds, n, rays, tmin, tmax, out);
     HIPCHK(hipGetLastError());
     return RT_OK;
@@ -342,7 +401,7 @@ extern "C" int rt_trace_primary(rt_ctx* c, int w, int h, float s_off, float t_of
     if (!frame_ok(w, h) || !prim || !t) { rt_set_error("rt_trace_primary: bad arguments"); return RT_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
     dim3 grid(n_tiles(w, h));
-    if (c->has_bvh) trace_primary_kernel<true><<<grid, RT_BLOCK, 0, c->stream>>>(c->ds, w, h, s_off, t_off, prim, t);
+    if (c->has_bvh) trace_primary_kernel<true><<<grid, RT_BLOCK, stack_bytes(c), c->stream>>>(c->ds, w, h, s_off, t_off, prim, t);
     else trace_primary_kernel<false><<<grid, RT_BLOCK, 0, c->stream>>>(c->ds, w, h, s_off, t_off, prim, t);
     HIPCHK(hipGetLastError());
     return RT_OK;
@@ -365,7 +424,8 @@ extern "C" int rt_render_accumulate(rt_ctx* c, int w, int h, uint32_t s0, uint32
     dim3 grid(n_tiles(w, h));
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     HIPCHK(hipEventRecord(e0, c->stream));
-#define RT_LAUNCH(B, G) render_kernel<B, G><<<grid, RT_BLOCK, 0, c->stream>>>(c->ds, w, h, s0, s1, k0, k1, max_depth, accum, c->d_counters)
+    const size_t lds = RT_BLOCK * sizeof(int) + stack_bytes(c);
+#define RT_LAUNCH(B, G) render_kernel<B, G><<<grid, RT_BLOCK, lds, c->stream>>>(c->ds, w, h, s0, s1, k0, k1, max_depth, accum, c->d_counters)
     if (c->has_bvh) { if (background == RT_BG_BLACK) RT_LAUNCH(true, RT_BG_BLACK); else RT_LAUNCH(true, RT_BG_SKY); }
     else            { if (background == RT_BG_BLACK) RT_LAUNCH(false, RT_BG_BLACK); else RT_LAUNCH(false, RT_BG_SKY); }
 #undef RT_LAUNCH
@@ -429,6 +489,16 @@ extern "C" int rt_get_counters(rt_ctx* c, rt_counters* out)
     return RT_OK;
 }
 
+#ifdef RT_STAMPS
+extern "C" int rt_debug_stamps(rt_ctx* c, unsigned long long* out12)
+{
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out12, c->d_counters + 4, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+#endif
+
 extern "C" int rt_reset_counters(rt_ctx* c)
 {
     if (!c) { rt_set_error("rt_reset_counters: null context"); return RT_ERR_ARG; }
@@ -436,7 +506,7 @@ extern "C" int rt_reset_counters(rt_ctx* c)
     HIPCHK(hipStreamSynchronize(c->stream));
     int rc = drain_events(c);
     if (rc) return rc;
-    HIPCHK(hipMemset(c->d_counters, 0, 2 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(c->d_counters, 0, RT_N_COUNTERS * sizeof(unsigned long long)));
     c->render_ms = c->last_ms = 0.0;
     c->launches = 0;
     return RT_OK;

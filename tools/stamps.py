@@ -1,0 +1,25 @@
+"""Section shares of the render loop from the diagnostic (-DRT_STAMPS) build: RT_AMD_LIB=tools/diag/librt_amd_stamps.so"""
+import ctypes as C, importlib.util, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("RT_AMD_LIB", os.path.join(ROOT, "tools/diag/librt_amd_stamps.so"))
+spec = importlib.util.spec_from_file_location("rtb", os.path.join(ROOT, "cuda-raytracer_amd/binding.py")); B = importlib.util.module_from_spec(spec); spec.loader.exec_module(B)
+import torch
+name = sys.argv[1] if len(sys.argv) > 1 else "cornell"
+W, H, spp = int(sys.argv[2]) if len(sys.argv) > 2 else 1024, int(sys.argv[3]) if len(sys.argv) > 3 else 1024, int(sys.argv[4]) if len(sys.argv) > 4 else 64
+param = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+sc = B.Scene(name, W, H, param)
+ctx = B.Context(0)
+ctx.upload(sc)
+acc = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
+ctx.render_accumulate(acc, W, H, 0, 2, 419, 100, sc.background)
+ctx.synchronize(); ctx.reset_counters()
+ctx.render_accumulate(acc, W, H, 2, 2 + spp, 419, 100, sc.background)
+c = ctx.counters()
+out = (C.c_ulonglong * 12)()
+B.lib().rt_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
+B.lib().rt_debug_stamps(ctx.handle, out)
+names = ["regen", "closest_hit", "rebuild", "ball", "tail", "scatter+rest"]
+tot = sum(out[:6]) or 1
+print("%s %dx%d@%d: %.1f ms, %.1f Mrays/s, rays %d" % (name, W, H, spp, c.last_render_ms, c.rays / c.last_render_ms / 1e3, c.rays))
+for n, v in zip(names, out[:6]):
+    print("  %-14s %5.1f %%   %8.0f cycles per wave-step (rays/64)" % (n, 100.0 * v / tot, v / (c.rays / 64.0)))
