@@ -32,6 +32,7 @@ struct DScene {
     const uint8_t*     __restrict__ image;
     const DNode*       __restrict__ nodes;   /* 64-byte two-box nodes (rt_host.h) */
     const DObj*        __restrict__ leafs;   /* BVH leaf table: first 64 bytes of each row are read */
+    const DProg*       __restrict__ prog;    /* the world list as 32-byte scan records (rt_host.h) */
     int32_t world;
     int32_t n_media;
     rt_camera cam;
@@ -233,16 +234,6 @@ __device__ __forceinline__ void apply_op(int type, float a, float b, float c3, D
         r.o.x = ox; r.o.z = oz; r.d.x = dx; r.d.z = dz;
     }
 }
-/* k-th wrapper op of object o, outermost first: the first two sit in the row itself */
-struct OpV { int type; float a, b, c; };
-__device__ __forceinline__ OpV obj_op(const DScene& S, const DObj& o, int k)
-{
-    OpV v;
-    if (k == 0) { v.type = (int)((o.head >> 24) & 0xfu); v.a = o.op0[0]; v.b = o.op0[1]; v.c = o.op0[2]; }
-    else if (k == 1) { v.type = (int)((o.head >> 28) & 0xfu); v.a = o.op1[0]; v.b = o.op1[1]; v.c = o.op1[2]; }
-    else { const rt_xform_op p = S.ops[o.op_begin + k]; v.type = p.type; v.a = p.a; v.b = p.b; v.c = p.c; }
-    return v;
-}
 __device__ __forceinline__ void apply_chain(const DScene& S, const DObj& o, DRay& r)
 {
     const int n = obj_op_count(o.head);
@@ -251,38 +242,37 @@ __device__ __forceinline__ void apply_chain(const DScene& S, const DObj& o, DRay
     for (int k = 2; k < n; ++k) { const rt_xform_op p = S.ops[o.op_begin + k]; apply_op(p.type, p.a, p.b, p.c, r); }
 }
 
-/* bare primitive (ray already in the object's frame): t only */
+/* bare primitive (ray already in the object's frame): t only.  F = the RT_F_* features compiled in. */
+template <uint32_t F>
 __device__ __forceinline__ bool prim_t(int type, const float* f, const DRay& r, float tMin, float tMax, float& t, int& aux)
 {
     aux = 0;
-    switch (type) {
-    case RT_OBJ_SPHERE:        return sphere_t(ld3(f), f[3], r, tMin, tMax, t);
-    case RT_OBJ_MOVING_SPHERE: return sphere_t(moving_centre(f, r.time), f[8], r, tMin, tMax, t);
-    case RT_OBJ_RECT_XY:
-    case RT_OBJ_RECT_XZ:
-    case RT_OBJ_RECT_YZ:       return rect_any_t(type, f, r, tMin, tMax, t);
-    case RT_OBJ_BOX:           return box_t(f, r, tMin, tMax, t, aux);
-    case RT_OBJ_TRIANGLE:      return triangle_t(f, r, tMin, tMax, t);
-    default: return false;
-    }
+    if ((F & RT_F_SPHERE) && type == RT_OBJ_SPHERE) return sphere_t(ld3(f), f[3], r, tMin, tMax, t);
+    if ((F & RT_F_MSPHERE) && type == RT_OBJ_MOVING_SPHERE) return sphere_t(moving_centre(f, r.time), f[8], r, tMin, tMax, t);
+    if ((F & RT_F_PLANAR) && type >= RT_OBJ_RECT_XY && type <= RT_OBJ_RECT_YZ) return rect_any_t(type, f, r, tMin, tMax, t);
+    if ((F & RT_F_PLANAR) && type == RT_OBJ_BOX) return box_t(f, r, tMin, tMax, t, aux);
+    if ((F & RT_F_TRI) && type == RT_OBJ_TRIANGLE) return triangle_t(f, r, tMin, tMax, t);
+    return false;
 }
 
 /* leaf with its own wrapper chain */
+template <uint32_t F>
 __device__ __forceinline__ bool leaf_t(const DScene& S, const DObj& o, DRay r, float tMin, float tMax, float& t, int& aux)
 {
-    apply_chain(S, o, r);
-    return prim_t(obj_type(o.head), o.f, r, tMin, tMax, t, aux);
+    if (F & RT_F_XFORM) apply_chain(S, o, r);
+    return prim_t<F>(obj_type(o.head), o.f, r, tMin, tMax, t, aux);
 }
 
 /* ConstantMedium::hit Volumes.cuh:26-49 (ray already in the medium's frame) */
+template <uint32_t F>
 __device__ __forceinline__ bool medium_t(const DScene& S, const DObj& o, const DRay& r, float tMin, float tMax,
                                          const PathRng& g, uint32_t bounce, float& t_out)
 {
     const DObj& b = S.objs[o.child_begin];
     float t1, t2;
     int unused;
-    if (!leaf_t(S, b, r, -FLT_MAX, FLT_MAX, t1, unused)) return false;
-    if (!leaf_t(S, b, r, t1 + .0001f, FLT_MAX, t2, unused)) return false;
+    if (!leaf_t<F>(S, b, r, -FLT_MAX, FLT_MAX, t1, unused)) return false;
+    if (!leaf_t<F>(S, b, r, t1 + .0001f, FLT_MAX, t2, unused)) return false;
     if (t1 < tMin) t1 = tMin;
     if (t2 > tMax) t2 = tMax;
     if (t1 >= t2) return false;
@@ -314,6 +304,7 @@ __device__ __forceinline__ bool slab(const float* bmin, const float* bmax, V3 o,
 /* Closest hit over one BVH (while-while traversal): the inner loop walks interior nodes until this
  * lane holds a leaf, then the leaf's primitives are tested; the per-lane stack lives in LDS,
  * entry i at stack[i * RT_BLOCK].  Near child first, far child pushed, best.t shrinking. */
+template <uint32_t F>
 __device__ __forceinline__ void bvh_closest(const DScene& S, int gi, int root, const DRay& r, float tMin,
                                             HitLite& best, int* stack)
 {
@@ -348,8 +339,8 @@ __device__ __forceinline__ void bvh_closest(const DScene& S, int gi, int root, c
             const DObj& lf = S.leafs[first + i];
             float t; int aux;
             bool h;
-            if (obj_op_count(lf.head) == 0) h = prim_t(obj_type(lf.head), lf.f, r, tMin, best.t, t, aux);
-            else h = leaf_t(S, S.objs[lf.prim_id], r, tMin, best.t, t, aux);     /* wrapped leaf: full row */
+            if (!(F & RT_F_XFORM) || obj_op_count(lf.head) == 0) h = prim_t<F>(obj_type(lf.head), lf.f, r, tMin, best.t, t, aux);
+            else h = leaf_t<F>(S, S.objs[lf.prim_id], r, tMin, best.t, t, aux);     /* wrapped leaf: full row */
             if (h) { best.t = t; best.obj = lf.prim_id; best.grp = gi; best.aux = aux; }
         }
         ref = RT_REF_NONE;
@@ -359,86 +350,180 @@ __device__ __forceinline__ void bvh_closest(const DScene& S, int gi, int root, c
 }
 
 /* ------------------------------------------------------------ closest hit ---- */
-template <bool HAS_BVH>
+/* one object through its row: a group (BVH or list), a medium, or a wrapped / bare leaf */
+template <uint32_t F>
 __device__ __forceinline__ void group_closest(const DScene& S, int gi, const DObj& g, DRay r, float tMin,
                                               HitLite& best, const PathRng* rng, uint32_t bounce, int* stack)
 {
-    apply_chain(S, g, r);
-    if (HAS_BVH && (obj_flags(g.head) & RT_DOBJ_HAS_BVH)) {
-        bvh_closest(S, gi, g.bvh_root, r, tMin, best, stack);
+    if (F & RT_F_XFORM) apply_chain(S, g, r);
+    if ((F & RT_F_BVH) && (obj_flags(g.head) & RT_DOBJ_HAS_BVH)) {
+        bvh_closest<F>(S, gi, g.bvh_root, r, tMin, best, stack);
         return;
     }
+    if (!(F & RT_F_GROUPLIST) && gi >= 0) return;
     for (int i = 0; i < g.child_count; ++i) {
         int oi = g.child_begin + i;
         const DObj& o = S.objs[oi];
         float t; int aux;
-        if (obj_type(o.head) == RT_OBJ_MEDIUM) {
+        if ((F & RT_F_MEDIA) && obj_type(o.head) == RT_OBJ_MEDIUM) {
             if (rng) {
                 DRay rm = r;
-                apply_chain(S, o, rm);
-                if (medium_t(S, o, rm, tMin, best.t, *rng, bounce, t)) { best.t = t; best.obj = oi; best.grp = gi; best.aux = 0; }
+                if (F & RT_F_XFORM) apply_chain(S, o, rm);
+                if (medium_t<F>(S, o, rm, tMin, best.t, *rng, bounce, t)) { best.t = t; best.obj = oi; best.grp = gi; best.aux = 0; }
             }
-        } else if (leaf_t(S, o, r, tMin, best.t, t, aux)) { best.t = t; best.obj = oi; best.grp = gi; best.aux = aux; }
+        } else if (leaf_t<F>(S, o, r, tMin, best.t, t, aux)) { best.t = t; best.obj = oi; best.grp = gi; best.aux = aux; }
     }
 }
 
-/* HitableList::hit over the world (HitableList.cuh:17-32): list order, tMax shrinks */
-template <bool HAS_BVH>
+template <uint32_t F>
+__device__ __forceinline__ void generic_closest(const DScene& S, int oi, const DRay& r, float tMin, HitLite& best,
+                                                const PathRng* rng, uint32_t bounce, int* stack)
+{
+    const DObj& o = S.objs[oi];
+    const int ty = obj_type(o.head);
+    float t; int aux;
+    if (ty == RT_OBJ_GROUP) {
+        if (F & (RT_F_BVH | RT_F_GROUPLIST)) group_closest<F>(S, oi, o, r, tMin, best, rng, bounce, stack);
+    } else if (ty == RT_OBJ_MEDIUM) {
+        if ((F & RT_F_MEDIA) && rng) {
+            DRay rm = r;
+            if (F & RT_F_XFORM) apply_chain(S, o, rm);
+            if (medium_t<F>(S, o, rm, tMin, best.t, *rng, bounce, t)) { best.t = t; best.obj = oi; best.grp = -1; best.aux = 0; }
+        }
+    } else if (leaf_t<F>(S, o, r, tMin, best.t, t, aux)) { best.t = t; best.obj = oi; best.grp = -1; best.aux = aux; }
+}
+
+/* one 32-byte scan record, fetched through the scalar cache */
+struct ProgRec { uint32_t head; int32_t obj; float v0, v1, v2, v3, v4, v5; };
+__device__ __forceinline__ ProgRec prog_load(const DProg* p)
+{
+    const uint4 a = reinterpret_cast<const uint4*>(p)[0], b = reinterpret_cast<const uint4*>(p)[1];
+    ProgRec r;
+    r.head = a.x; r.obj = (int32_t)a.y;
+    r.v0 = __uint_as_float(a.z); r.v1 = __uint_as_float(a.w);
+    r.v2 = __uint_as_float(b.x); r.v3 = __uint_as_float(b.y); r.v4 = __uint_as_float(b.z); r.v5 = __uint_as_float(b.w);
+    return r;
+}
+
+/* HitableList::hit over the world (HitableList.cuh:17-32): list order, tMax shrinks.  The list is run
+ * as the scan program of rt_host.h: every lane of the wave executes the same record, so records come
+ * through the scalar cache and the next one is requested before the current one is evaluated. */
+template <uint32_t F>
 __device__ __forceinline__ HitLite closest_hit(const DScene& S, const DRay& r, float tMin, float tMax,
                                                const PathRng* rng, uint32_t bounce, int* stack)
 {
     HitLite best = {tMax, -1, -1, 0};
-    const DObj& w = S.objs[S.world];
-    if (HAS_BVH && (obj_flags(w.head) & RT_DOBJ_HAS_BVH)) {
-        group_closest<HAS_BVH>(S, -1, w, r, tMin, best, rng, bounce, stack);
-        return best;
+    if (F & RT_F_BVH) {
+        const DObj& w = S.objs[S.world];
+        if (obj_flags(w.head) & RT_DOBJ_HAS_BVH) {
+            group_closest<F>(S, -1, w, r, tMin, best, rng, bounce, stack);
+            return best;
+        }
     }
-    for (int i = 0; i < w.child_count; ++i) {
-        int oi = w.child_begin + i;
-        const DObj& o = S.objs[oi];
-        const int ty = obj_type(o.head);
-        float t; int aux;
-        if (ty == RT_OBJ_GROUP) {
-            group_closest<HAS_BVH>(S, oi, o, r, tMin, best, rng, bounce, stack);
-        } else if (ty == RT_OBJ_MEDIUM) {
-            if (rng) {
-                DRay rm = r;
-                apply_chain(S, o, rm);
-                if (medium_t(S, o, rm, tMin, best.t, *rng, bounce, t)) { best.t = t; best.obj = oi; best.grp = -1; best.aux = 0; }
+    DRay rl = r;                                   /* the ray in the current record's frame */
+    const DProg* pc = S.prog;
+    ProgRec cur = prog_load(pc);
+    while (true) {
+        const int kind = (int)(cur.head & 0xffu);
+        if (kind == RT_P_END) break;
+        ++pc;
+        const ProgRec nxt = prog_load(pc);
+        if (kind == RT_P_RECT) {
+            if (F & RT_F_PLANAR) {
+                const int ka = (int)((cur.head >> 8) & 0xffu);
+                float t;
+                bool h;
+                if (ka == 2) h = rect_t<2>(cur.v1, cur.v2, cur.v3, cur.v4, cur.v0, rl, tMin, best.t, t);
+                else if (ka == 1) h = rect_t<1>(cur.v1, cur.v2, cur.v3, cur.v4, cur.v0, rl, tMin, best.t, t);
+                else h = rect_t<0>(cur.v1, cur.v2, cur.v3, cur.v4, cur.v0, rl, tMin, best.t, t);
+                if (h) { best.t = t; best.obj = cur.obj; best.grp = -1; best.aux = (int)((cur.head >> 16) & 0xffu); }
+            }
+        } else if (kind == RT_P_XFORM) {
+            if (F & RT_F_XFORM) {
+                rl = r;
+                const int n = (int)((cur.head >> 8) & 0xffu);
+                if (n > 0) apply_op((int)((cur.head >> 16) & 0xfu), cur.v0, cur.v1, cur.v2, rl);
+                if (n > 1) apply_op((int)((cur.head >> 20) & 0xfu), cur.v3, cur.v4, cur.v5, rl);
+            }
+        } else if (kind == RT_P_SPHERE) {
+            if (F & RT_F_SPHERE) {
+                float t;
+                if (sphere_t(mk(cur.v0, cur.v1, cur.v2), cur.v3, rl, tMin, best.t, t)) { best.t = t; best.obj = cur.obj; best.grp = -1; best.aux = 0; }
             }
         } else {
-            const bool h_ = leaf_t(S, o, r, tMin, best.t, t, aux);
-            if (h_) { best.t = t; best.obj = oi; best.grp = -1; best.aux = aux; }
+            generic_closest<F>(S, cur.obj, r, tMin, best, rng, bounce, stack);
         }
+        cur = nxt;
     }
     return best;
 }
 
 /* --------------------------------------------------- rebuild the record ---- */
-/* combined wrapper chain of the winner: the group's ops then the leaf's, outermost first */
-__device__ __forceinline__ OpV chain_op(const DScene& S, const DObj& grp, int gc, const DObj& o, int k)
+/* What rebuild needs of the winner's row and of its group's row, fetched by the lane in ONE round
+ * trip (every address is known from the HitLite) instead of field by field along the way. */
+struct RowRegs {
+    uint32_t head; int32_t material, prim_id;
+    float f[13];
+    float op0[3], op1[3];
+    int32_t op_begin;
+};
+template <uint32_t F, bool FULL>
+__device__ __forceinline__ void row_load(const DObj* p, RowRegs& w)
 {
-    return k < gc ? obj_op(S, grp, k) : obj_op(S, o, k - gc);
+    const float4* q = reinterpret_cast<const float4*>(p);
+    const float4 a = q[0], b = q[1], c = q[2];
+    w.head = __float_as_uint(a.x); w.material = __float_as_int(a.y); w.prim_id = __float_as_int(a.z);
+    w.f[0] = a.w; w.f[1] = b.x; w.f[2] = b.y; w.f[3] = b.z; w.f[4] = b.w;
+    w.f[5] = c.x; w.f[6] = c.y; w.f[7] = c.z; w.f[8] = c.w;
+    if (FULL && (F & (RT_F_TRI | RT_F_MSPHERE))) { const float4 d = q[3]; w.f[9] = d.x; w.f[10] = d.y; w.f[11] = d.z; w.f[12] = d.w; }
+    else { w.f[9] = w.f[10] = w.f[11] = w.f[12] = 0.f; }
+    if (F & RT_F_XFORM) {
+        const float4 e = q[4], g = q[5];
+        w.op0[0] = e.x; w.op0[1] = e.y; w.op0[2] = e.z; w.op1[0] = e.w; w.op1[1] = g.x; w.op1[2] = g.y;
+        w.op_begin = __float_as_int(g.z);
+    } else {
+        w.op0[0] = w.op0[1] = w.op0[2] = w.op1[0] = w.op1[1] = w.op1[2] = 0.f;
+        w.op_begin = 0;
+    }
+}
+struct OpV { int type; float a, b, c; };
+template <uint32_t F>
+__device__ __forceinline__ OpV row_op(const DScene& S, const RowRegs& o, int k)
+{
+    OpV v;
+    if (k == 0) { v.type = (int)((o.head >> 24) & 0xfu); v.a = o.op0[0]; v.b = o.op0[1]; v.c = o.op0[2]; }
+    else if (k == 1 || !(F & RT_F_LONGCHAIN)) { v.type = (int)((o.head >> 28) & 0xfu); v.a = o.op1[0]; v.b = o.op1[1]; v.c = o.op1[2]; }
+    else { const rt_xform_op p = S.ops[o.op_begin + k]; v.type = p.type; v.a = p.a; v.b = p.b; v.c = p.c; }
+    return v;
+}
+/* combined wrapper chain of the winner: the group's ops then the leaf's, outermost first */
+template <uint32_t F>
+__device__ __forceinline__ OpV chain_op(const DScene& S, const RowRegs& grp, int gc, const RowRegs& o, int k)
+{
+    return k < gc ? row_op<F>(S, grp, k) : row_op<F>(S, o, k - gc);
 }
 
-template <bool WANT_UV>
+template <uint32_t F, bool WANT_UV>
 __device__ __forceinline__ void rebuild(const DScene& S, const DRay& world_ray, const HitLite& hl, float tMin, HitRec& h)
 {
-    const DObj& o = S.objs[hl.obj];
-    const DObj& grp = S.objs[hl.grp >= 0 ? hl.grp : hl.obj];
-    const int gc = hl.grp >= 0 ? obj_op_count(grp.head) : 0;
-    const int n = gc + obj_op_count(o.head);
+    RowRegs o, grp;
+    row_load<F, true>(S.objs + hl.obj, o);
+    const bool in_group = (F & (RT_F_BVH | RT_F_GROUPLIST)) && hl.grp >= 0;
+    if (F & (RT_F_BVH | RT_F_GROUPLIST)) row_load<F, false>(S.objs + (in_group ? hl.grp : hl.obj), grp);
+    else grp = o;
+    const int gc = in_group ? obj_op_count(grp.head) : 0;
+    const int n = (F & RT_F_XFORM) ? gc + obj_op_count(o.head) : 0;
     DRay r = world_ray;
-    for (int k = 0; k < n; ++k) { const OpV op = chain_op(S, grp, gc, o, k); apply_op(op.type, op.a, op.b, op.c, r); }
+    for (int k = 0; k < n; ++k) { const OpV op = chain_op<F>(S, grp, gc, o, k); apply_op(op.type, op.a, op.b, op.c, r); }
 
     const float t = hl.t;
     h.t = t; h.u = 0.f; h.v = 0.f; h.front = 0;
     h.material = o.material;
     h.prim_id = o.prim_id;
     /* u,v feed image textures only (Texture.cuh:49-61); the render kernel skips them otherwise */
-    const bool want_uv = WANT_UV || (S.mats[o.material].pad != 0);
+    const bool want_uv = WANT_UV || ((F & RT_F_IMAGE) && S.mats[o.material].pad != 0);
     const int ty = obj_type(o.head);
-    if (ty >= RT_OBJ_RECT_XY && ty <= RT_OBJ_BOX) {
+    if ((F & RT_F_PLANAR) && ty >= RT_OBJ_RECT_XY && ty <= RT_OBJ_BOX) {
         /* the three rect kinds and the six box faces (Box.cuh:24-36) through one body */
         const float* f = o.f;
         const bool box = ty == RT_OBJ_BOX;
@@ -450,7 +535,7 @@ __device__ __forceinline__ void rebuild(const DScene& S, const DRay& world_ray, 
         const float b1 = box ? (KA == 2 ? f[4] : f[5]) : f[3];
         rect_rec<WANT_UV>(KA, a0, a1, b0, b1, r, t, want_uv, h);
         if (box && (face & 1)) h.front = !h.front;          /* FlipNormals, Surface.cuh:24 */
-    } else if (ty == RT_OBJ_SPHERE) {
+    } else if ((F & RT_F_SPHERE) && ty == RT_OBJ_SPHERE) {
         V3 centre = ld3(o.f);
         h.p = at(r, t);
         h.n = (h.p - centre) / o.f[3];
@@ -461,11 +546,11 @@ __device__ __forceinline__ void rebuild(const DScene& S, const DRay& world_ray, 
             h.u = (float)(1 - (phi + RT_PI_D) / (2 * RT_PI_D));
             h.v = (float)((theta + RT_PI_D / 2) / RT_PI_D);
         }
-    } else if (ty == RT_OBJ_MOVING_SPHERE) {
+    } else if ((F & RT_F_MSPHERE) && ty == RT_OBJ_MOVING_SPHERE) {
         V3 centre = moving_centre(o.f, r.time);
         h.p = at(r, t);
         h.n = (h.p - centre) / o.f[8];
-    } else if (ty == RT_OBJ_TRIANGLE) {
+    } else if ((F & RT_F_TRI) && ty == RT_OBJ_TRIANGLE) {
         V3 normal = ld3(o.f + 9);
         h.p = at(r, t);
         h.n = dot(normal, r.d) > 0 ? -normal : normal;      /* Triangle.cuh:38-41 */
@@ -478,14 +563,14 @@ __device__ __forceinline__ void rebuild(const DScene& S, const DRay& world_ray, 
 
     /* unwind the wrappers, innermost first (Transform.cuh:24, :101-108) */
     for (int k = n - 1; k >= 0; --k) {
-        const OpV op = chain_op(S, grp, gc, o, k);
+        const OpV op = chain_op<F>(S, grp, gc, o, k);
         if (op.type == RT_OP_TRANSLATE) {
             h.p = h.p + mk(op.a, op.b, op.c);
         } else {
             /* direction of the ray as this RotateY saw it after rotating: ops 0..k applied */
             V3 d = world_ray.d;
             for (int j = 0; j <= k; ++j) {
-                const OpV oj = chain_op(S, grp, gc, o, j);
+                const OpV oj = chain_op<F>(S, grp, gc, o, j);
                 if (oj.type == RT_OP_ROTATE_Y) {
                     float dx = oj.b * d.x - oj.a * d.z, dz = oj.a * d.x + oj.b * d.z;
                     d.x = dx; d.z = dz;
@@ -505,15 +590,18 @@ __device__ __forceinline__ void rebuild(const DScene& S, const DRay& world_ray, 
 }
 
 /* --------------------------------------------------------------- textures ---- */
+template <uint32_t F>
 __device__ __forceinline__ V3 texture_value(const DScene& S, int ti, float u, float v, V3 p)
 {
     rt_texture t = S.texs[ti];
     /* CheckerTexture::value Texture.cuh:31-36 (checkers may nest) */
-    for (int guard = 0; guard < 8 && t.type == RT_TEX_CHECKER; ++guard) {
-        float sines = sinf(10 * p.x) * sinf(10 * p.y) * sinf(10 * p.z);
-        t = S.texs[sines < 0 ? t.odd : t.even];
+    if (F & RT_F_CHECKER) {
+        for (int guard = 0; guard < 8 && t.type == RT_TEX_CHECKER; ++guard) {
+            float sines = sinf(10 * p.x) * sinf(10 * p.y) * sinf(10 * p.z);
+            t = S.texs[sines < 0 ? t.odd : t.even];
+        }
     }
-    if (t.type == RT_TEX_IMAGE) {                            /* ImageTexture::value Texture.cuh:49-61 */
+    if ((F & RT_F_IMAGE) && t.type == RT_TEX_IMAGE) {                            /* ImageTexture::value Texture.cuh:49-61 */
         const uint8_t* data = S.image + t.image_offset;
         int i = (int)(u * t.width);
         int j = (int)((1 - v) * t.height - .001f);
@@ -618,6 +706,7 @@ __device__ __forceinline__ bool refract(V3 v, V3 n, float niOverNt, V3& refracte
 /* Material::scatter + emitted (Material.cuh:51-144). Returns false when the path ends. */
 /* `ball` = randomInUnitSphere() for this bounce, drawn by the caller (random_in_unit_sphere_wave) when the
  * material is Lambert, Metal or Isotropic */
+template <uint32_t F>
 __device__ __forceinline__ bool scatter(const DScene& S, const DRay& in, const HitRec& rec, const PathRng& g,
                                         uint32_t bounce, V3 ball, V3& attenuation, DRay& out, V3& emitted)
 {
@@ -625,21 +714,25 @@ __device__ __forceinline__ bool scatter(const DScene& S, const DRay& in, const H
     emitted = mk(0.f, 0.f, 0.f);
     attenuation = mk(0.f, 0.f, 0.f);
     out.o = rec.p;
+    out.d = mk(0.f, 0.f, 1.f);
     out.time = in.time;
-    switch (m.type) {
-    case RT_MAT_LAMBERT: {
+    if (m.type == RT_MAT_LAMBERT) {
         V3 target = rec.p + rec.n + ball;
         out.d = target - rec.p;
-        attenuation = texture_value(S, m.texture, rec.u, rec.v, rec.p);
+        attenuation = texture_value<F>(S, m.texture, rec.u, rec.v, rec.p);
         return true;
     }
-    case RT_MAT_METAL: {
+    if (m.type == RT_MAT_LIGHT) {
+        emitted = texture_value<F>(S, m.texture, rec.u, rec.v, rec.p);
+        return false;
+    }
+    if ((F & RT_F_METAL) && m.type == RT_MAT_METAL) {
         V3 reflected = reflect(unit(in.d), rec.n);
         out.d = reflected + m.param * ball;
-        attenuation = texture_value(S, m.texture, 0, 0, rec.p);
+        attenuation = texture_value<F>(S, m.texture, 0, 0, rec.p);
         return dot(out.d, rec.n) > 0.f;
     }
-    case RT_MAT_GLASS: {
+    if ((F & RT_F_GLASS) && m.type == RT_MAT_GLASS) {
         float refIdx = m.param;
         V3 outwardNorm;
         V3 reflected = reflect(in.d, rec.n);
@@ -661,24 +754,23 @@ __device__ __forceinline__ bool scatter(const DScene& S, const DRay& in, const H
         out.d = rt_u32_to_uniform(rng_block(g, RT_RNG_GLASS, bounce, 0u).x) < reflectProb ? reflected : refracted;
         return true;
     }
-    case RT_MAT_LIGHT:
-        emitted = texture_value(S, m.texture, rec.u, rec.v, rec.p);
-        return false;
-    default: /* Isotropic: time resets to 0 (Material.cuh:140) */
+    if (F & RT_F_ISO) { /* Isotropic: time resets to 0 (Material.cuh:140) */
         out.d = ball;
         out.time = 0.f;
-        attenuation = texture_value(S, m.texture, rec.u, rec.v, rec.p);
+        attenuation = texture_value<F>(S, m.texture, rec.u, rec.v, rec.p);
         return true;
     }
+    return false;
 }
 
 /* ------------------------------------------------------------------ camera ---- */
+template <uint32_t F>
 __device__ __forceinline__ DRay generate_ray(const rt_camera& c, float s, float t, float xi_time, const PathRng& g)   /* Camera.cuh:40-46 */
 {
     /* randomInUnitDisk (Camera.cuh:12-18).  Its result is multiplied by lensRadius, and its draws are
      * addressed blocks of their own, so a pinhole camera skips the loop without changing any other draw. */
     V3 p = mk(0.f, 0.f, 0.f);
-    if (c.lens_radius != 0.f) {
+    if ((F & RT_F_LENS) && c.lens_radius != 0.f) {
         uint32_t k = 0;
         do {
             rt_u32x4 w = rng_block(g, RT_RNG_DISK, 0u, k++);

@@ -186,6 +186,109 @@ bool rt_pack_bvh(const rt_flat_scene* s, std::vector<DObj>& objs, std::vector<DN
     return true;
 }
 
+void rt_pack_program(const rt_flat_scene* s, std::vector<DProg>& prog)
+{
+    prog.clear();
+    const rt_object& w = s->objects[s->world];
+    /* the wrapper chain the scan's local ray currently has: starts as the world frame */
+    int cur_n = 0;
+    rt_xform_op cur[2];
+    std::memset(cur, 0, sizeof cur);
+    auto same_chain = [&](const rt_object& o) {
+        if (o.op_count != cur_n) return false;
+        for (int k = 0; k < cur_n; ++k)
+            if (std::memcmp(&s->ops[o.op_begin + k], &cur[k], sizeof(rt_xform_op)) != 0) return false;
+        return true;
+    };
+    for (int i = 0; i < w.child_count; ++i) {
+        const int oi = w.child_begin + i;
+        const rt_object& o = s->objects[oi];
+        DProg r;
+        std::memset(&r, 0, sizeof r);
+        r.obj = oi;
+        const bool simple = (o.type == RT_OBJ_SPHERE || (o.type >= RT_OBJ_RECT_XY && o.type <= RT_OBJ_BOX)) && o.op_count <= 2;
+        if (!simple) { r.head = RT_P_GENERIC; prog.push_back(r); continue; }
+        if (!same_chain(o)) {
+            DProg x;
+            std::memset(&x, 0, sizeof x);
+            x.obj = oi;
+            cur_n = o.op_count;
+            uint32_t ty[2] = {0, 0};
+            for (int k = 0; k < cur_n; ++k) {
+                cur[k] = s->ops[o.op_begin + k];
+                ty[k] = (uint32_t)cur[k].type;
+                x.v[3 * k] = cur[k].a; x.v[3 * k + 1] = cur[k].b; x.v[3 * k + 2] = cur[k].c;
+            }
+            x.head = RT_P_XFORM | ((uint32_t)cur_n << 8) | (ty[0] << 16) | (ty[1] << 20);
+            prog.push_back(x);
+        }
+        const float* f = o.f;
+        if (o.type == RT_OBJ_SPHERE) {
+            r.head = RT_P_SPHERE;
+            for (int k = 0; k < 4; ++k) r.v[k] = f[k];
+            prog.push_back(r);
+        } else if (o.type == RT_OBJ_BOX) {
+            /* Box.cuh:24-36: z = p1.z, z = p0.z, y = p1.y, y = p0.y, x = p1.x, x = p0.x */
+            const int   axis[6] = {2, 2, 1, 1, 0, 0};
+            const float k6[6]   = {f[5], f[2], f[4], f[1], f[3], f[0]};
+            for (int face = 0; face < 6; ++face) {
+                const int ka = axis[face];
+                r.head = RT_P_RECT | ((uint32_t)ka << 8) | ((uint32_t)face << 16);
+                r.v[0] = k6[face];
+                r.v[1] = ka == 0 ? f[1] : f[0]; r.v[2] = ka == 0 ? f[4] : f[3];
+                r.v[3] = ka == 2 ? f[1] : f[2]; r.v[4] = ka == 2 ? f[4] : f[5];
+                prog.push_back(r);
+            }
+        } else {
+            const int ka = RT_OBJ_RECT_YZ - o.type;   /* XY -> 2, XZ -> 1, YZ -> 0 */
+            r.head = RT_P_RECT | ((uint32_t)ka << 8);
+            r.v[0] = f[4]; r.v[1] = f[0]; r.v[2] = f[1]; r.v[3] = f[2]; r.v[4] = f[3];
+            prog.push_back(r);
+        }
+    }
+    DProg e;
+    std::memset(&e, 0, sizeof e);
+    e.head = RT_P_END;
+    prog.push_back(e);
+    prog.push_back(e);   /* the scan prefetches one record past the one it runs */
+}
+
+uint32_t rt_scene_features(const rt_flat_scene* s)
+{
+    uint32_t f = 0;
+    for (int i = 0; i < s->n_objects; ++i) {
+        const rt_object& o = s->objects[i];
+        if (o.op_count > 0) f |= RT_F_XFORM;
+        if (o.op_count > 2) f |= RT_F_LONGCHAIN;
+        switch (o.type) {
+        case RT_OBJ_SPHERE: f |= RT_F_SPHERE; break;
+        case RT_OBJ_MOVING_SPHERE: f |= RT_F_MSPHERE; break;
+        case RT_OBJ_RECT_XY: case RT_OBJ_RECT_XZ: case RT_OBJ_RECT_YZ: case RT_OBJ_BOX: f |= RT_F_PLANAR; break;
+        case RT_OBJ_TRIANGLE: f |= RT_F_TRI; break;
+        case RT_OBJ_MEDIUM: f |= RT_F_MEDIA; break;
+        case RT_OBJ_GROUP:
+            if (o.bvh_root >= 0) f |= RT_F_BVH;
+            else if (i != s->world) f |= RT_F_GROUPLIST;
+            break;
+        default: break;
+        }
+    }
+    for (int i = 0; i < s->n_materials; ++i) {
+        switch (s->materials[i].type) {
+        case RT_MAT_GLASS: f |= RT_F_GLASS; break;
+        case RT_MAT_METAL: f |= RT_F_METAL; break;
+        case RT_MAT_ISOTROPIC: f |= RT_F_ISO; break;
+        default: break;
+        }
+    }
+    for (int i = 0; i < s->n_textures; ++i) {
+        if (s->textures[i].type == RT_TEX_CHECKER) f |= RT_F_CHECKER;
+        if (s->textures[i].type == RT_TEX_IMAGE) f |= RT_F_IMAGE;
+    }
+    if (s->camera.lens_radius != 0.f) f |= RT_F_LENS;
+    return f;
+}
+
 extern "C" int rt_quantise_rgb8(const float* rgb, int width, int height, uint8_t* out)
 {
     if (!rgb || !out || width <= 0 || height <= 0) { rt_set_error("rt_quantise_rgb8: bad arguments"); return RT_ERR_ARG; }

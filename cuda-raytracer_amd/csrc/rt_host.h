@@ -37,6 +37,38 @@ struct alignas(16) DNode {
     int32_t left, right;
     int32_t pad[2];
 };
+/* The world list as a linear program of 32-byte records, read wave-uniformly (one s_load_dwordx8
+ * each, the next one prefetched) by the closest-hit scan.  A Box is six RECT records in the order of
+ * Box.cuh:24-36; consecutive objects under the same wrapper chain share one XFORM record; everything
+ * else (groups, media, moving spheres, triangles, chains longer than two) is a GENERIC record that
+ * sends the scan through the object's row. */
+enum { RT_P_END = 0, RT_P_XFORM = 1, RT_P_RECT = 2, RT_P_SPHERE = 3, RT_P_GENERIC = 4 };
+struct alignas(32) DProg {
+    uint32_t head;   /* kind | XFORM: nops<<8 | op0 type<<16 | op1 type<<20 ; RECT: axis<<8 | face<<16 */
+    int32_t  obj;    /* object index (RECT/SPHERE/GENERIC) */
+    float    v[6];   /* XFORM: op0 abc, op1 abc; RECT: k a0 a1 b0 b1; SPHERE: cx cy cz r */
+};
+
+/* scene feature bits: a render kernel is compiled for a set of them and leaves the rest out */
+enum {
+    RT_F_BVH = 1u << 0,      /* some group has a BVH */
+    RT_F_GROUPLIST = 1u << 1,/* some group is scanned as a list */
+    RT_F_MEDIA = 1u << 2,
+    RT_F_SPHERE = 1u << 3,
+    RT_F_MSPHERE = 1u << 4,
+    RT_F_TRI = 1u << 5,
+    RT_F_PLANAR = 1u << 6,   /* rects and boxes */
+    RT_F_LONGCHAIN = 1u << 7,/* a wrapper chain longer than two ops */
+    RT_F_LENS = 1u << 8,     /* camera aperture > 0 */
+    RT_F_GLASS = 1u << 9,
+    RT_F_METAL = 1u << 10,
+    RT_F_ISO = 1u << 11,
+    RT_F_CHECKER = 1u << 12,
+    RT_F_IMAGE = 1u << 13,
+    RT_F_XFORM = 1u << 14,   /* any wrapper op at all */
+    RT_F_ALL = (1u << 15) - 1
+};
+
 #define RT_REF_NONE ((int32_t)0x80000000)
 #define RT_MAX_LEAF 16
 #define RT_MAX_STACK 64
@@ -58,5 +90,11 @@ void rt_pack_objects(const rt_flat_scene* s, DObj* out);
 #include <vector>
 bool rt_pack_bvh(const rt_flat_scene* s, std::vector<DObj>& objs, std::vector<DNode>& nodes,
                  std::vector<DObj>& leafs_full, int* depth, std::string& why);
+
+/* the world list -> program records (terminated by one RT_P_END record) */
+void rt_pack_program(const rt_flat_scene* s, std::vector<DProg>& prog);
+
+/* RT_F_* bits the scene uses */
+uint32_t rt_scene_features(const rt_flat_scene* s);
 
 #endif

@@ -20,7 +20,17 @@
 #include "rt_device.h"
 #include "rt_host.h"
 
+/* feature sets the render kernel is compiled for (rt_host.h RT_F_*); a scene runs on the first one
+ * that covers it.  Leaving out what a scene cannot contain keeps the kernel's register and
+ * instruction-cache footprint down; the arithmetic of what remains is unchanged. */
+#define RT_V_PLANAR       (RT_F_PLANAR | RT_F_XFORM)                                   /* Cornell box */
+#define RT_V_PLANAR_MEDIA (RT_F_PLANAR | RT_F_XFORM | RT_F_MEDIA | RT_F_ISO)           /* Cornell smoke */
+#define RT_V_LIST         (RT_F_ALL & ~RT_F_BVH)                                       /* any scene without a BVH */
+#define RT_V_BVH_TRI      (RT_F_BVH | RT_F_TRI | RT_F_PLANAR)                          /* triangle mesh + area light */
 #define RT_N_COUNTERS 16        /* rays, samples, then diagnostic slots */
+#ifndef RT_RENDER_WAVES_BVH
+#define RT_RENDER_WAVES_BVH 3  /* BVH variants: <=168 VGPRs, no spills */
+#endif
 #ifndef RT_RENDER_WAVES
 #define RT_RENDER_WAVES 4      /* waves per SIMD the render kernel is compiled for (<=128 VGPRs) */
 #endif
@@ -38,12 +48,12 @@
 #endif
 
 /* ------------------------------------------------------------------ kernels -- */
-template <bool HAS_BVH>
+template <uint32_t F>
 __global__ __launch_bounds__(RT_BLOCK) void trace_rays_kernel(DScene S, int n, const float* __restrict__ rays,
                                                                float tmin, float tmax, rt_hit_record* __restrict__ out)
 {
-    extern __shared__ int stack_mem[];                 /* HAS_BVH: stack_depth x RT_BLOCK ints */
-    int* stack = stack_mem + (HAS_BVH ? threadIdx.x : 0);
+    extern __shared__ int stack_mem[];                 /* RT_F_BVH: stack_depth x RT_BLOCK ints */
+    int* stack = stack_mem + ((F & RT_F_BVH) ? threadIdx.x : 0);
     int i = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (i >= n) return;
     const float* q = rays + 7 * (size_t)i;
@@ -51,13 +61,13 @@ __global__ __launch_bounds__(RT_BLOCK) void trace_rays_kernel(DScene S, int n, c
     r.o = mk(q[0], q[1], q[2]);
     r.d = mk(q[3], q[4], q[5]);
     r.time = q[6];
-    HitLite hl = closest_hit<HAS_BVH>(S, r, tmin, tmax, nullptr, 0u, stack);
+    HitLite hl = closest_hit<F>(S, r, tmin, tmax, nullptr, 0u, stack);
     rt_hit_record o;
     memset(&o, 0, sizeof o);
     o.prim = -1;
     if (hl.obj >= 0) {
         HitRec h;
-        rebuild<true>(S, r, hl, tmin, h);
+        rebuild<F, true>(S, r, hl, tmin, h);
         o.hit = 1; o.prim = h.prim_id; o.t = h.t; o.u = h.u; o.v = h.v;
         o.p[0] = h.p.x; o.p[1] = h.p.y; o.p[2] = h.p.z;
         o.n[0] = h.n.x; o.n[1] = h.n.y; o.n[2] = h.n.z;
@@ -84,33 +94,33 @@ __device__ __forceinline__ int xcd_tile(int b, int nb)
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
-template <bool HAS_BVH>
+template <uint32_t F>
 __global__ __launch_bounds__(RT_BLOCK) void trace_primary_kernel(DScene S, int W, int H, float s_off, float t_off,
                                                                   int32_t* __restrict__ prim, float* __restrict__ t_out)
 {
     extern __shared__ int stack_mem[];
-    int* stack = stack_mem + (HAS_BVH ? threadIdx.x : 0);
+    int* stack = stack_mem + ((F & RT_F_BVH) ? threadIdx.x : 0);
     int i, j;
     tile_pixel(W, xcd_tile(blockIdx.x, gridDim.x), threadIdx.x, i, j);
     if (i >= W || j >= H) return;
     float u = float(i + s_off) / float(W);
     float v = float(j + t_off) / float(H);
     DRay r = primary_ray(S.cam, u, v);
-    HitLite hl = closest_hit<HAS_BVH>(S, r, .001f, FLT_MAX, nullptr, 0u, stack);
+    HitLite hl = closest_hit<F>(S, r, .001f, FLT_MAX, nullptr, 0u, stack);
     size_t px = (size_t)j * W + i;
     prim[px] = hl.obj >= 0 ? S.objs[hl.obj].prim_id : -1;
     t_out[px] = hl.obj >= 0 ? hl.t : 0.f;
 }
 
-template <bool HAS_BVH, int BG>
-__global__ __launch_bounds__(RT_BLOCK, RT_RENDER_WAVES) void render_kernel(DScene S, int W, int H, uint32_t s_begin, uint32_t s_end,
+template <uint32_t F, int BG>
+__global__ __launch_bounds__(RT_BLOCK, (F & RT_F_BVH) ? RT_RENDER_WAVES_BVH : RT_RENDER_WAVES) void render_kernel(DScene S, int W, int H, uint32_t s_begin, uint32_t s_end,
                                                            uint32_t k0, uint32_t k1, int max_depth,
                                                            float* __restrict__ accum,
                                                            unsigned long long* __restrict__ counters)
 {
-    extern __shared__ int stack_mem[];                 /* RT_BLOCK ints, then HAS_BVH: stack_depth x RT_BLOCK */
+    extern __shared__ int stack_mem[];                 /* RT_BLOCK ints, then RT_F_BVH: stack_depth x RT_BLOCK */
     int* slots = stack_mem + (threadIdx.x & ~63u);     /* 64 ints per wave for the wave-wide ball draw */
-    int* stack = stack_mem + RT_BLOCK + (HAS_BVH ? threadIdx.x : 0);
+    int* stack = stack_mem + RT_BLOCK + ((F & RT_F_BVH) ? threadIdx.x : 0);
     int i, j;
     tile_pixel(W, xcd_tile(blockIdx.x, gridDim.x), threadIdx.x, i, j);
     const bool valid = i < W && j < H;
@@ -136,7 +146,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_RENDER_WAVES) void render_kernel(DScen
             rt_u32x4 cw = rng_block(g, RT_RNG_CAMERA, 0u, 0u);
             float u = float(i + rt_u32_to_uniform(cw.x)) / float(W);
             float v = float(j + rt_u32_to_uniform(cw.y)) / float(H);
-            ray = generate_ray(S.cam, u, v, rt_u32_to_uniform(cw.z), g);
+            ray = generate_ray<F>(S.cam, u, v, rt_u32_to_uniform(cw.z), g);
             att = mk(1.f, 1.f, 1.f);
             emi = mk(0.f, 0.f, 0.f);
             depth = 0;
@@ -150,7 +160,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_RENDER_WAVES) void render_kernel(DScen
          * made by all 64 lanes together. */
         HitLite hl = {FLT_MAX, -1, -1, 0};
         if (alive) {
-            hl = closest_hit<HAS_BVH>(S, ray, .001f, FLT_MAX, &g, (uint32_t)depth, stack);
+            hl = closest_hit<F>(S, ray, .001f, FLT_MAX, &g, (uint32_t)depth, stack);
             ++n_rays;
         }
         RT_STAMP(1)
@@ -160,11 +170,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_RENDER_WAVES) void render_kernel(DScen
         rec.material = 0; rec.prim_id = -1; rec.front = 0;
         int mtype = RT_MAT_LIGHT;
         if (hit) {
-            rebuild<false>(S, ray, hl, .001f, rec);
+            rebuild<F, false>(S, ray, hl, .001f, rec);
             mtype = S.mats[rec.material].type;
         }
         RT_STAMP(2)
-        const bool need_ball = hit && (mtype == RT_MAT_LAMBERT || mtype == RT_MAT_METAL || mtype == RT_MAT_ISOTROPIC);
+        const bool need_ball = hit && mtype != RT_MAT_LIGHT && mtype != RT_MAT_GLASS;
         const V3 ball = random_in_unit_sphere_wave(g, (uint32_t)depth, need_ball, slots);
         RT_STAMP(3)
         if (alive) {
@@ -173,7 +183,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_RENDER_WAVES) void render_kernel(DScen
             if (hit) {
                 V3 attenuation, emitted;
                 DRay scattered;
-                if (scatter(S, ray, rec, g, (uint32_t)depth, ball, attenuation, scattered, emitted)) {
+                if (scatter<F>(S, ray, rec, g, (uint32_t)depth, ball, attenuation, scattered, emitted)) {
                     att = att * attenuation;
                     if (BG == RT_BG_BLACK) emi = emi + emitted * att;
                     ray = scattered;
@@ -247,10 +257,11 @@ struct rt_ctx {
     bool own_stream = false;
     bool have_scene = false;
     bool has_bvh = false;
+    uint32_t features = 0;    /* RT_F_* of the uploaded scene */
     int stack_depth = 0;      /* LDS stack entries per lane the uploaded BVHs need */
     DScene ds;
     void* d_objs = nullptr;  void* d_ops = nullptr;   void* d_mats = nullptr; void* d_texs = nullptr;
-    void* d_image = nullptr; void* d_nodes = nullptr; void* d_leafs = nullptr;
+    void* d_image = nullptr; void* d_nodes = nullptr; void* d_leafs = nullptr; void* d_prog = nullptr;
     unsigned long long* d_counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     /* render launches whose event pair has not been read back yet are timed lazily */
@@ -261,7 +272,7 @@ struct rt_ctx {
 
 static void free_scene(rt_ctx* c)
 {
-    void** ptrs[] = {&c->d_objs, &c->d_ops, &c->d_mats, &c->d_texs, &c->d_image, &c->d_nodes, &c->d_leafs};
+    void** ptrs[] = {&c->d_objs, &c->d_ops, &c->d_mats, &c->d_texs, &c->d_image, &c->d_nodes, &c->d_leafs, &c->d_prog};
     for (void** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
     c->have_scene = false;
 }
@@ -323,6 +334,8 @@ extern "C" int rt_scene_upload(rt_ctx* c, const rt_flat_scene* s)
     std::vector<DObj> leafs;
     int stack_depth = 0;
     if (!rt_pack_bvh(s, objs, nodes, leafs, &stack_depth, why)) { rt_set_error("rt_scene_upload: " + why); return RT_ERR_UNSUPPORTED; }
+    std::vector<DProg> prog;
+    rt_pack_program(s, prog);
     if (stack_depth > RT_MAX_STACK) { rt_set_error("rt_scene_upload: BVH deeper than the traversal stack (64)"); return RT_ERR_UNSUPPORTED; }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -351,7 +364,8 @@ extern "C" int rt_scene_upload(rt_ctx* c, const rt_flat_scene* s)
     if ((rc = upload(c, &c->d_image, s->image_bytes, (size_t)s->n_image_bytes))) return rc;
     if ((rc = upload(c, &c->d_nodes, nodes.data(), nodes.size()))) return rc;
     if ((rc = upload(c, &c->d_leafs, leafs.data(), leafs.size()))) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream)); /* objs, nodes, leafs and mats are locals */
+    if ((rc = upload(c, &c->d_prog, prog.data(), prog.size()))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream)); /* objs, nodes, leafs, prog and mats are locals */
     c->ds.objs = (const DObj*)c->d_objs;
     c->ds.ops = (const rt_xform_op*)c->d_ops;
     c->ds.mats = (const rt_material*)c->d_mats;
@@ -359,6 +373,8 @@ extern "C" int rt_scene_upload(rt_ctx* c, const rt_flat_scene* s)
     c->ds.image = (const uint8_t*)c->d_image;
     c->ds.nodes = (const DNode*)c->d_nodes;
     c->ds.leafs = (const DObj*)c->d_leafs;
+    c->ds.prog = (const DProg*)c->d_prog;
+    c->features = rt_scene_features(s);
     c->ds.world = s->world;
     c->ds.n_media = s->n_media;
     c->ds.cam = s->camera;
@@ -385,8 +401,8 @@ extern "C" int rt_trace_rays(rt_ctx* c, int n, const float* rays, float tmin, fl
     if (n == 0) return RT_OK;
     HIPCHK(hipSetDevice(c->device));
     dim3 grid((unsigned)((n + RT_BLOCK - 1) / RT_BLOCK));
-    if (c->has_bvh) trace_rays_kernel<true><<<grid, RT_BLOCK, stack_bytes(c), c->stream>>>(c->ds, n, rays, tmin, tmax, out);
-    else trace_rays_kernel<false><<<grid, RT_BLOCK, 0, c->stream>>>(c->ds, n, rays, tmin, tmax, out);
+    if (c->has_bvh) trace_rays_kernel<RT_F_ALL><<<grid, RT_BLOCK, stack_bytes(c), c->stream>>>(c->ds, n, rays, tmin, tmax, out);
+    else trace_rays_kernel<RT_V_LIST><<<grid, RT_BLOCK, 0, c->stream>>>(c->ds, n, rays, tmin, tmax, out);
     HIPCHK(hipGetLastError());
     return RT_OK;
 }
@@ -401,8 +417,8 @@ extern "C" int rt_trace_primary(rt_ctx* c, int w, int h, float s_off, float t_of
     if (!frame_ok(w, h) || !prim || !t) { rt_set_error("rt_trace_primary: bad arguments"); return RT_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
     dim3 grid(n_tiles(w, h));
-    if (c->has_bvh) trace_primary_kernel<true><<<grid, RT_BLOCK, stack_bytes(c), c->stream>>>(c->ds, w, h, s_off, t_off, prim, t);
-    else trace_primary_kernel<false><<<grid, RT_BLOCK, 0, c->stream>>>(c->ds, w, h, s_off, t_off, prim, t);
+    if (c->has_bvh) trace_primary_kernel<RT_F_ALL><<<grid, RT_BLOCK, stack_bytes(c), c->stream>>>(c->ds, w, h, s_off, t_off, prim, t);
+    else trace_primary_kernel<RT_V_LIST><<<grid, RT_BLOCK, 0, c->stream>>>(c->ds, w, h, s_off, t_off, prim, t);
     HIPCHK(hipGetLastError());
     return RT_OK;
 }
@@ -425,9 +441,20 @@ extern "C" int rt_render_accumulate(rt_ctx* c, int w, int h, uint32_t s0, uint32
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     HIPCHK(hipEventRecord(e0, c->stream));
     const size_t lds = RT_BLOCK * sizeof(int) + stack_bytes(c);
-#define RT_LAUNCH(B, G) render_kernel<B, G><<<grid, RT_BLOCK, lds, c->stream>>>(c->ds, w, h, s0, s1, k0, k1, max_depth, accum, c->d_counters)
-    if (c->has_bvh) { if (background == RT_BG_BLACK) RT_LAUNCH(true, RT_BG_BLACK); else RT_LAUNCH(true, RT_BG_SKY); }
-    else            { if (background == RT_BG_BLACK) RT_LAUNCH(false, RT_BG_BLACK); else RT_LAUNCH(false, RT_BG_SKY); }
+    /* the smallest compiled feature set that covers the scene */
+    static const uint32_t variants[] = {RT_V_PLANAR, RT_V_PLANAR_MEDIA, RT_V_LIST, RT_V_BVH_TRI, RT_F_ALL};
+    uint32_t pick = RT_F_ALL;
+    for (uint32_t v : variants) if ((c->features & ~v) == 0) { pick = v; break; }
+#define RT_LAUNCH(V, G) render_kernel<V, G><<<grid, RT_BLOCK, lds, c->stream>>>(c->ds, w, h, s0, s1, k0, k1, max_depth, accum, c->d_counters)
+#define RT_LAUNCH_BG(V) { if (background == RT_BG_BLACK) RT_LAUNCH(V, RT_BG_BLACK); else RT_LAUNCH(V, RT_BG_SKY); }
+    switch (pick) {
+    case RT_V_PLANAR:       RT_LAUNCH_BG(RT_V_PLANAR) break;
+    case RT_V_PLANAR_MEDIA: RT_LAUNCH_BG(RT_V_PLANAR_MEDIA) break;
+    case RT_V_LIST:         RT_LAUNCH_BG(RT_V_LIST) break;
+    case RT_V_BVH_TRI:      RT_LAUNCH_BG(RT_V_BVH_TRI) break;
+    default:                RT_LAUNCH_BG(RT_F_ALL) break;
+    }
+#undef RT_LAUNCH_BG
 #undef RT_LAUNCH
     hipError_t le = hipGetLastError();
     HIPCHK(hipEventRecord(e1, c->stream));
