@@ -200,14 +200,17 @@ void rt_pack_program(const rt_flat_scene* s, std::vector<DProg>& prog)
             if (std::memcmp(&s->ops[o.op_begin + k], &cur[k], sizeof(rt_xform_op)) != 0) return false;
         return true;
     };
-    for (int i = 0; i < w.child_count; ++i) {
+    /* a world that has a BVH of its own is traversed directly: no scan records */
+    for (int i = 0; i < (w.bvh_root >= 0 ? 0 : w.child_count); ++i) {
         const int oi = w.child_begin + i;
         const rt_object& o = s->objects[oi];
         DProg r;
         std::memset(&r, 0, sizeof r);
         r.obj = oi;
         const bool simple = (o.type == RT_OBJ_SPHERE || (o.type >= RT_OBJ_RECT_XY && o.type <= RT_OBJ_BOX)) && o.op_count <= 2;
-        if (!simple) { r.head = RT_P_GENERIC; prog.push_back(r); continue; }
+        /* a GENERIC record may leave the scan's local ray in its own frame (a BVH group is traversed in
+         * place by the wavefront intersect kernel): the next simple object re-establishes its frame */
+        if (!simple) { r.head = RT_P_GENERIC; prog.push_back(r); cur_n = -1; continue; }
         if (!same_chain(o)) {
             DProg x;
             std::memset(&x, 0, sizeof x);

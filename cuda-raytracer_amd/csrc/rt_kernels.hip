@@ -522,6 +522,7 @@ extern "C" int rt_debug_stamps(rt_ctx* c, unsigned long long* out12)
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out12, c->d_counters + 4, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyFromSymbol(out12 + 6, HIP_SYMBOL(rt_dbg_counts), 4 * sizeof(unsigned long long)));
     return RT_OK;
 }
 #endif

@@ -11,15 +11,24 @@ sc = B.Scene(name, W, H, param)
 ctx = B.Context(0)
 ctx.upload(sc)
 acc = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
+B.lib().rt_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
 ctx.render_accumulate(acc, W, H, 0, 2, 419, 100, sc.background)
-ctx.synchronize(); ctx.reset_counters()
+ctx.synchronize()
+base = (C.c_ulonglong * 12)()
+B.lib().rt_debug_stamps(ctx.handle, base)
+ctx.reset_counters()
 ctx.render_accumulate(acc, W, H, 2, 2 + spp, 419, 100, sc.background)
 c = ctx.counters()
 out = (C.c_ulonglong * 12)()
-B.lib().rt_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
 B.lib().rt_debug_stamps(ctx.handle, out)
+for q in range(6, 10):
+    out[q] -= base[q]      # the device-global loop counters are not reset with the context's
 names = ["regen", "closest_hit", "rebuild", "ball", "tail", "scatter+rest"]
 tot = sum(out[:6]) or 1
 print("%s %dx%d@%d: %.1f ms, %.1f Mrays/s, rays %d" % (name, W, H, spp, c.last_render_ms, c.rays / c.last_render_ms / 1e3, c.rays))
 for n, v in zip(names, out[:6]):
     print("  %-14s %5.1f %%   %8.0f cycles per wave-step (rays/64)" % (n, 100.0 * v / tot, v / (c.rays / 64.0)))
+if out[6]:
+    r = float(c.rays)
+    print("  BVH: %.1f node visits and %.1f leaf tests per ray" % (out[6] / r, out[7] / r))
+    print("       lane efficiency of the node loop %.2f, of the leaf loop %.2f" % (out[6] / max(1, out[8]), out[7] / max(1, out[9])))
