@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--param", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--integrator", default="auto", choices=["auto", "megakernel", "wavefront"])
     args = ap.parse_args()
 
     import torch
@@ -139,6 +140,7 @@ def main():
     stream = torch.cuda.current_stream(dev)
     ctx = b.Context(local_rank, stream.cuda_stream)
     ctx.upload(scene)
+    ctx.set_integrator({"auto": 0, "megakernel": 1, "wavefront": 2}[args.integrator])
     accum = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
     rgb = None
 

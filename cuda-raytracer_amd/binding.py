@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")   # RT_AMD_LIB: diagnostic builds (tools/diag)
 
 RT_BG_BLACK, RT_BG_SKY = 0, 1
+RT_INTEGRATOR_AUTO, RT_INTEGRATOR_MEGAKERNEL, RT_INTEGRATOR_WAVEFRONT = 0, 1, 2
 
 
 class Vec3(C.Structure):
@@ -76,7 +77,7 @@ EXPORTS = [
     "rt_last_error", "rt_scene_create_builtin", "rt_scene_from_flat", "rt_scene_flat",
     "rt_scene_default_background", "rt_scene_destroy", "rt_ctx_create", "rt_ctx_destroy",
     "rt_scene_upload", "rt_trace_rays", "rt_trace_primary", "rt_render_accumulate", "rt_resolve",
-    "rt_synchronize", "rt_get_counters", "rt_reset_counters", "rt_quantise_rgb8", "rt_write_ppm",
+    "rt_ctx_set_integrator", "rt_synchronize", "rt_get_counters", "rt_reset_counters", "rt_quantise_rgb8", "rt_write_ppm",
 ]
 
 
@@ -105,6 +106,7 @@ def load_library(path=LIB_PATH):
     lib.rt_trace_primary.argtypes = [vp, i32, i32, f32, f32, vp, vp]
     lib.rt_render_accumulate.argtypes = [vp, i32, i32, u32, u32, u64, i32, i32, vp]
     lib.rt_resolve.argtypes = [vp, vp, i32, i32, u32, i32, vp]
+    lib.rt_ctx_set_integrator.argtypes = [vp, i32]
     lib.rt_synchronize.argtypes = [vp]
     lib.rt_get_counters.argtypes = [vp, C.POINTER(RtCounters)]
     lib.rt_reset_counters.argtypes = [vp]
@@ -201,6 +203,9 @@ class Context:
         rgb = torch.empty_like(accum)
         _check(lib().rt_resolve(self.handle, accum.data_ptr(), width, height, spp, 1 if gamma else 0, rgb.data_ptr()), "rt_resolve")
         return rgb
+
+    def set_integrator(self, mode):
+        _check(lib().rt_ctx_set_integrator(self.handle, mode), "rt_ctx_set_integrator")
 
     def synchronize(self):
         _check(lib().rt_synchronize(self.handle), "rt_synchronize")

@@ -19,6 +19,7 @@
 #include "../../include/rt_api.h"
 #include "rt_device.h"
 #include "rt_host.h"
+#include "rt_wavefront.h"
 
 /* feature sets the render kernel is compiled for (rt_host.h RT_F_*); a scene runs on the first one
  * that covers it.  Leaving out what a scene cannot contain keeps the kernel's register and
@@ -258,6 +259,12 @@ struct rt_ctx {
     bool have_scene = false;
     bool has_bvh = false;
     uint32_t features = 0;    /* RT_F_* of the uploaded scene */
+    int integrator = RT_INTEGRATOR_AUTO;
+    /* wavefront path state (rt_wavefront.h), allocated on first use and kept */
+    WfState wf = {};
+    void* wf_mem = nullptr;
+    size_t wf_slots_cap = 0;
+    uint32_t* wf_host_count = nullptr;   /* pinned */
     int stack_depth = 0;      /* LDS stack entries per lane the uploaded BVHs need */
     DScene ds;
     void* d_objs = nullptr;  void* d_ops = nullptr;   void* d_mats = nullptr; void* d_texs = nullptr;
@@ -309,6 +316,8 @@ extern "C" void rt_ctx_destroy(rt_ctx* c)
     for (auto& p : c->pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     free_scene(c);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->wf_mem) (void)hipFree(c->wf_mem);
+    if (c->wf_host_count) (void)hipHostFree(c->wf_host_count);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -423,6 +432,85 @@ extern "C" int rt_trace_primary(rt_ctx* c, int w, int h, float s_off, float t_of
     return RT_OK;
 }
 
+/* ------------------------------------------------------------ wavefront host -- */
+__global__ void wf_reset_kernel(uint32_t* count, int which) { count[which] = 0u; count[2] = 0u; }
+
+static int wf_reserve(rt_ctx* c, size_t n_slots)
+{
+    if (!c->wf_host_count) HIPCHK(hipHostMalloc((void**)&c->wf_host_count, 4 * sizeof(uint32_t), hipHostMallocDefault));
+    if (n_slots > c->wf_slots_cap) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->wf_mem) { (void)hipFree(c->wf_mem); c->wf_mem = nullptr; c->wf_slots_cap = 0; }
+        const size_t bytes = n_slots * (6 * sizeof(float4) + 2 * sizeof(uint32_t)) + 256;
+        HIPCHK(hipMalloc(&c->wf_mem, bytes));
+        c->wf_slots_cap = n_slots;
+    }
+    /* carve: six float4 arrays, two queues, then the counters */
+    char* p = (char*)c->wf_mem;
+    const size_t cap = c->wf_slots_cap;
+    c->wf.ray_o = (float4*)p; p += cap * sizeof(float4);
+    c->wf.ray_d = (float4*)p; p += cap * sizeof(float4);
+    c->wf.att   = (float4*)p; p += cap * sizeof(float4);
+    c->wf.emi   = (float4*)p; p += cap * sizeof(float4);
+    c->wf.sum   = (float4*)p; p += cap * sizeof(float4);
+    c->wf.hit   = (float4*)p; p += cap * sizeof(float4);
+    c->wf.queue[0] = (uint32_t*)p; p += cap * sizeof(uint32_t);
+    c->wf.queue[1] = (uint32_t*)p; p += cap * sizeof(uint32_t);
+    c->wf.count = (uint32_t*)p;
+    return RT_OK;
+}
+
+template <uint32_t V>
+static int wf_run(rt_ctx* c, int w, int h, uint32_t s0, uint32_t s1, uint32_t k0, uint32_t k1, int max_depth,
+                  int background, float* accum)
+{
+    const uint32_t n_pixels = (uint32_t)w * (uint32_t)h;
+    /* about a million paths in flight: K sample streams per pixel, never more than there are samples */
+    uint32_t streams = ((1u << 20) + n_pixels - 1) / n_pixels;
+    if (streams > s1 - s0) streams = s1 - s0;
+    if (streams < 1) streams = 1;
+    const size_t n_slots = (size_t)n_pixels * streams;
+    int rc = wf_reserve(c, n_slots);
+    if (rc) return rc;
+    WfState& W = c->wf;
+    W.n_slots = (uint32_t)n_slots; W.n_pixels = n_pixels; W.streams = streams;
+    const size_t lds = (size_t)c->stack_depth * RT_BLOCK * sizeof(int);
+    HIPCHK(hipMemsetAsync(W.count, 0, 4 * sizeof(uint32_t), c->stream));
+    const unsigned all_blocks = (unsigned)((n_slots + RT_BLOCK - 1) / RT_BLOCK);
+    wf_init_kernel<V><<<dim3(all_blocks), RT_BLOCK, 0, c->stream>>>(c->ds, W, w, h, s0, s1, k0, k1, max_depth, c->d_counters);
+    HIPCHK(hipGetLastError());
+    uint32_t known = (uint32_t)n_slots;      /* upper bound of the current queue's length (it never grows) */
+    int cur = 0;
+    const int batch = 4;
+    while (known > 0) {
+        for (int b = 0; b < batch; ++b) {
+            wf_reset_kernel<<<1, 1, 0, c->stream>>>(W.count, cur ^ 1);
+            unsigned blocks = (known + RT_BLOCK - 1) / RT_BLOCK;
+            unsigned iblocks = blocks < 2048u ? blocks : 2048u;
+            wf_intersect_kernel<V><<<dim3(iblocks), RT_BLOCK, lds, c->stream>>>(c->ds, W, cur, k0, k1, c->d_counters);
+            if (background == RT_BG_BLACK)
+                wf_logic_kernel<V, RT_BG_BLACK><<<dim3(blocks), RT_BLOCK, 0, c->stream>>>(c->ds, W, cur, w, h, s1, k0, k1, max_depth);
+            else
+                wf_logic_kernel<V, RT_BG_SKY><<<dim3(blocks), RT_BLOCK, 0, c->stream>>>(c->ds, W, cur, w, h, s1, k0, k1, max_depth);
+            cur ^= 1;
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(c->wf_host_count, W.count, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        known = c->wf_host_count[cur];
+    }
+    wf_finalize_kernel<<<dim3((n_pixels + RT_BLOCK - 1) / RT_BLOCK), RT_BLOCK, 0, c->stream>>>(W, accum);
+    HIPCHK(hipGetLastError());
+    return RT_OK;
+}
+
+extern "C" int rt_ctx_set_integrator(rt_ctx* c, int mode)
+{
+    if (!c || mode < RT_INTEGRATOR_AUTO || mode > RT_INTEGRATOR_WAVEFRONT) { rt_set_error("rt_ctx_set_integrator: bad arguments"); return RT_ERR_ARG; }
+    c->integrator = mode;
+    return RT_OK;
+}
+
 extern "C" int rt_render_accumulate(rt_ctx* c, int w, int h, uint32_t s0, uint32_t s1, uint64_t seed, int max_depth,
                                     int background, float* accum)
 {
@@ -440,6 +528,14 @@ extern "C" int rt_render_accumulate(rt_ctx* c, int w, int h, uint32_t s0, uint32
     dim3 grid(n_tiles(w, h));
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     HIPCHK(hipEventRecord(e0, c->stream));
+    const bool wavefront = c->integrator == RT_INTEGRATOR_WAVEFRONT || (c->integrator == RT_INTEGRATOR_AUTO && c->has_bvh);
+    if (wavefront) {
+        int wrc = (c->features & ~RT_V_BVH_TRI) == 0 ? wf_run<RT_V_BVH_TRI>(c, w, h, s0, s1, k0, k1, max_depth, background, accum)
+                                                     : wf_run<RT_F_ALL>(c, w, h, s0, s1, k0, k1, max_depth, background, accum);
+        HIPCHK(hipEventRecord(e1, c->stream));
+        c->pending.push_back({e0, e1});
+        return wrc;
+    }
     const size_t lds = RT_BLOCK * sizeof(int) + stack_bytes(c);
     /* the smallest compiled feature set that covers the scene */
     static const uint32_t variants[] = {RT_V_PLANAR, RT_V_PLANAR_MEDIA, RT_V_LIST, RT_V_BVH_TRI, RT_F_ALL};

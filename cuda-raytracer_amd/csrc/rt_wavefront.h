@@ -1,0 +1,377 @@
+/*
+ * rt_wavefront.h — the wavefront form of the path tracer, used for scenes with a BVH.
+ *
+ * The reference's `render` (main.cu:125-198) and the megakernel in rt_kernels.hip keep a path in one
+ * lane from camera to termination.  On a BVH scene the closest-hit query dominates and its cost per
+ * ray is heavy-tailed (1M-triangle scene: 43 traversal steps on average, several hundred for a grazing
+ * ray), so a wave that only refills its lanes between bounces runs its traversal loop with a few lanes
+ * live (measured 8 % in the node loop).  Here the path state lives in HBM and two kernels alternate:
+ *
+ *   wf_intersect  persistent waves; every lane is a small interpreter that advances ITS ray by one step
+ *                 per trip (a scan record of the world list, a BVH node, or one leaf primitive) and, the
+ *                 moment its ray is finished, takes the next ray from the queue — no lane waits for
+ *                 another lane's ray.
+ *   wf_logic      one lane per queued path: rebuild the hit record, scatter, accumulate, start the next
+ *                 sample of the slot when the path ends, and queue the slot again while it is alive.
+ *
+ * A slot owns a pixel and the sample indices s_begin + k, s_begin + k + K, ... (k = its stream), runs them
+ * one after another and keeps their sum; wf_finalize adds the K partial sums of a pixel in stream order,
+ * so the image is reproducible bit for bit from run to run.  The RNG is addressed by (pixel, sample,
+ * bounce), so every sample's path is the same one the megakernel and the oracle trace.
+ *
+ * State traffic is 6 x 16 B per slot read and written about once per ray: ~200 B/ray, against the
+ * ~2.8 KB/ray of BVH nodes and leaf rows the intersect kernel fetches on the triangle scene.
+ */
+#ifndef RT_WAVEFRONT_H
+#define RT_WAVEFRONT_H
+#include "rt_device.h"
+
+struct WfState {
+    float4* __restrict__ ray_o;   /* origin xyz, time */
+    float4* __restrict__ ray_d;   /* direction xyz, bounce index (bits) */
+    float4* __restrict__ att;     /* attenuation xyz, sample index in flight (bits) */
+    float4* __restrict__ emi;     /* emitted-so-far xyz, unused */
+    float4* __restrict__ sum;     /* radiance sum of the slot's finished samples xyz, unused */
+    float4* __restrict__ hit;     /* t, object, group, aux (bits) */
+    uint32_t* __restrict__ queue[2];
+    uint32_t* __restrict__ count; /* [0],[1] = entries of queue[0],queue[1]; [2] = intersect fetch head */
+    uint32_t n_slots, n_pixels, streams;
+};
+
+enum { WF_NEED = 0, WF_SCAN = 1, WF_BVH = 2 };
+
+/* ------------------------------------------------------------------ intersect -- */
+template <uint32_t F>
+__global__ __launch_bounds__(RT_BLOCK) void wf_intersect_kernel(DScene S, WfState W, int qi, uint32_t k0, uint32_t k1,
+                                                                unsigned long long* __restrict__ counters)
+{
+    extern __shared__ int stack_mem[];
+    int* stack = stack_mem + threadIdx.x;
+    const uint32_t n_queue = W.count[qi];
+    const uint32_t* __restrict__ queue = W.queue[qi];
+    const int lane = (int)(threadIdx.x & 63u);
+    const float tMin = .001f;
+    const uint32_t whead = S.objs[S.world].head;
+    const bool world_bvh = (obj_flags(whead) & RT_DOBJ_HAS_BVH) != 0;
+    const int world_root = S.objs[S.world].bvh_root;
+
+    int mode = WF_NEED;
+    uint32_t slot = 0;
+    DRay rw = {mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f), 0.f}, rl = rw;
+    V3 id = mk(0.f, 0.f, 0.f);
+    HitLite best = {FLT_MAX, -1, -1, 0};
+    int pc = 0, gi = -1, ref = RT_REF_NONE, sp = 0, li = 0;
+    PathRng g;
+    rng_start(g, k0, k1, 0u, 0u);
+    uint32_t bounce = 0;
+    uint32_t n_rays = 0;
+    bool drained = false;                       /* wave-uniform: the queue has nothing left */
+
+    while (true) {
+        /* ---- refill: lanes without a ray take the next queue entries, a wave-wide batch at a time ---- */
+        const unsigned long long need = __ballot(mode == WF_NEED);
+        const int n_need = __popcll(need);
+        if (!drained && (n_need >= 16 || n_need == 64)) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&W.count[2], (uint32_t)n_need);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (base + (uint32_t)n_need >= n_queue) drained = true;
+            if (mode == WF_NEED) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                const uint32_t e = base + rank;
+                if (e < n_queue) {
+                    slot = queue[e];
+                    const float4 o = W.ray_o[slot], d = W.ray_d[slot];
+                    rw.o = mk(o.x, o.y, o.z); rw.time = o.w;
+                    rw.d = mk(d.x, d.y, d.z);
+                    bounce = __float_as_uint(d.w);
+                    g.pixel = slot % W.n_pixels;
+                    g.sample = __float_as_uint(W.att[slot].w);
+                    best.t = FLT_MAX; best.obj = -1; best.grp = -1; best.aux = 0;
+                    rl = rw;
+                    sp = 0; li = 0;
+                    ++n_rays;
+                    if ((F & RT_F_BVH) && world_bvh) {
+                        mode = WF_BVH; gi = -1; ref = world_root; pc = -1;
+                        id = mk(1.f / rl.d.x, 1.f / rl.d.y, 1.f / rl.d.z);
+                    } else {
+                        mode = WF_SCAN; pc = 0;
+                    }
+                }
+            }
+        }
+        if (__ballot(mode != WF_NEED) == 0ull) {
+            if (drained) break;
+            continue;                            /* fewer than 16 idle lanes cannot happen here: all 64 are idle */
+        }
+
+        /* ---- one step: every busy lane fetches the 64 bytes its step reads ---- */
+        const bool in_bvh = mode == WF_BVH;
+        const bool interior = in_bvh && ref >= 0;
+        const int lfirst = (~ref) >> 4, lcount = ((~ref) & 15) + 1;
+        const float4* src = reinterpret_cast<const float4*>(S.prog);
+        if (mode == WF_SCAN) src = reinterpret_cast<const float4*>(S.prog + pc);
+        if (in_bvh) src = interior ? reinterpret_cast<const float4*>(S.nodes + ref)
+                                   : reinterpret_cast<const float4*>(S.leafs + (lfirst + li));
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0, q3 = q0;
+        if (mode != WF_NEED) { q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3]; }
+
+        if (in_bvh) {
+            if (interior) {
+                const float lmin[3] = {q0.x, q0.y, q0.z}, lmax[3] = {q0.w, q1.x, q1.y};
+                const float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
+                const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+                float tl, tr;
+                const bool hl = slab(lmin, lmax, rl.o, id, tMin, best.t, tl);
+                const bool hr = slab(rmin, rmax, rl.o, id, tMin, best.t, tr);
+                if (hl & hr) {
+                    const bool lnear = tl <= tr;
+                    stack[sp * RT_BLOCK] = lnear ? right : left;
+                    ++sp;
+                    ref = lnear ? left : right;
+                } else if (hl | hr) {
+                    ref = hl ? left : right;
+                } else {
+                    ref = RT_REF_NONE;
+                    if (sp > 0) { --sp; ref = stack[sp * RT_BLOCK]; }
+                }
+            } else {
+                const uint32_t head = __float_as_uint(q0.x);
+                const int oi = __float_as_int(q0.z);
+                const float f[13] = {q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+                float t; int aux;
+                bool h;
+                if (!(F & RT_F_XFORM) || obj_op_count(head) == 0) h = prim_t<F>(obj_type(head), f, rl, tMin, best.t, t, aux);
+                else h = leaf_t<F>(S, S.objs[oi], rl, tMin, best.t, t, aux);
+                if (h) { best.t = t; best.obj = oi; best.grp = gi; best.aux = aux; }
+                if (++li == lcount) {
+                    li = 0;
+                    ref = RT_REF_NONE;
+                    if (sp > 0) { --sp; ref = stack[sp * RT_BLOCK]; }
+                }
+            }
+            if (ref == RT_REF_NONE) { mode = WF_SCAN; ++pc; }     /* the group is done: on with the world list */
+        } else if (mode == WF_SCAN) {
+            const uint32_t head = __float_as_uint(q0.x);
+            const int kind = (int)(head & 0xffu);
+            const int obj = __float_as_int(q0.y);
+            if (kind == RT_P_END) {
+                W.hit[slot] = make_float4(best.t, __int_as_float(best.obj), __int_as_float(best.grp), __int_as_float(best.aux));
+                mode = WF_NEED;
+            } else if (kind == RT_P_RECT) {
+                if (F & RT_F_PLANAR) {
+                    const int ka = (int)((head >> 8) & 0xffu);
+                    /* run-time axis: pick the ray components, then the reference's arithmetic (Rectangle.cuh:24-38) */
+                    DRay ra;
+                    ra.o = mk(ka == 0 ? rl.o.y : rl.o.x, ka == 2 ? rl.o.y : rl.o.z, ka == 2 ? rl.o.z : (ka == 1 ? rl.o.y : rl.o.x));
+                    ra.d = mk(ka == 0 ? rl.d.y : rl.d.x, ka == 2 ? rl.d.y : rl.d.z, ka == 2 ? rl.d.z : (ka == 1 ? rl.d.y : rl.d.x));
+                    ra.time = rl.time;
+                    /* ra = (a, b, k) components; rect_t<2> reads a = x, b = y, k = z */
+                    float t;
+                    if (rect_t<2>(q0.w, q1.x, q1.y, q1.z, q0.z, ra, tMin, best.t, t)) {
+                        best.t = t; best.obj = obj; best.grp = -1; best.aux = (int)((head >> 16) & 0xffu);
+                    }
+                }
+                ++pc;
+            } else if (kind == RT_P_XFORM) {
+                if (F & RT_F_XFORM) {
+                    rl = rw;
+                    const int n = (int)((head >> 8) & 0xffu);
+                    if (n > 0) apply_op((int)((head >> 16) & 0xfu), q0.z, q0.w, q1.x, rl);
+                    if (n > 1) apply_op((int)((head >> 20) & 0xfu), q1.y, q1.z, q1.w, rl);
+                }
+                ++pc;
+            } else if (kind == RT_P_SPHERE) {
+                if (F & RT_F_SPHERE) {
+                    float t;
+                    if (sphere_t(mk(q0.z, q0.w, q1.x), q1.y, rl, tMin, best.t, t)) { best.t = t; best.obj = obj; best.grp = -1; best.aux = 0; }
+                }
+                ++pc;
+            } else { /* RT_P_GENERIC */
+                const DObj& o = S.objs[obj];
+                const uint32_t oh = o.head;
+                if ((F & RT_F_BVH) && obj_type(oh) == RT_OBJ_GROUP && (obj_flags(oh) & RT_DOBJ_HAS_BVH)) {
+                    rl = rw;
+                    if (F & RT_F_XFORM) apply_chain(S, o, rl);
+                    id = mk(1.f / rl.d.x, 1.f / rl.d.y, 1.f / rl.d.z);
+                    mode = WF_BVH; gi = obj; ref = o.bvh_root; sp = 0; li = 0;
+                    /* pc stays on this record; it advances when the traversal ends */
+                } else {
+                    generic_closest<F & ~RT_F_BVH>(S, obj, rw, tMin, best, &g, bounce, stack);
+                    ++pc;
+                }
+            }
+        }
+    }
+    unsigned long long r = n_rays;
+    for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off);
+    if (lane == 0) atomicAdd(&counters[0], r);
+}
+
+/* ---------------------------------------------------------------------- logic -- */
+/* slot -> pixel: stream k of pixel p is slot k * n_pixels + p */
+template <uint32_t F>
+__device__ __forceinline__ void wf_start_sample(const DScene& S, const WfState& W, uint32_t slot, uint32_t sample, int Wd, int Hd,
+                                                uint32_t k0, uint32_t k1, float4& o4, float4& d4, float4& a4, float4& e4)
+{
+    const uint32_t pixel = slot % W.n_pixels;
+    const int i = (int)(pixel % (uint32_t)Wd), j = (int)(pixel / (uint32_t)Wd);
+    PathRng g;
+    rng_start(g, k0, k1, pixel, sample);
+    rt_u32x4 cw = rng_block(g, RT_RNG_CAMERA, 0u, 0u);
+    float u = float(i + rt_u32_to_uniform(cw.x)) / float(Wd);
+    float v = float(j + rt_u32_to_uniform(cw.y)) / float(Hd);
+    DRay ray = generate_ray<F>(S.cam, u, v, rt_u32_to_uniform(cw.z), g);
+    o4 = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.time);
+    d4 = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(0u));
+    a4 = make_float4(1.f, 1.f, 1.f, __uint_as_float(sample));
+    e4 = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+/* wave-aggregated append of `slot` to a queue */
+__device__ __forceinline__ void wf_push(uint32_t* __restrict__ queue, uint32_t* __restrict__ count, bool want, uint32_t slot)
+{
+    const unsigned long long m = __ballot(want);
+    if (m == 0ull) return;
+    const int lane = (int)(threadIdx.x & 63u);
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader);
+    if (want) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        queue[base + rank] = slot;
+    }
+}
+
+/* first launch of a render call: every slot starts its first sample (or stays dead) */
+template <uint32_t F>
+__global__ __launch_bounds__(RT_BLOCK) void wf_init_kernel(DScene S, WfState W, int Wd, int Hd, uint32_t s_begin, uint32_t s_end,
+                                                           uint32_t k0, uint32_t k1, int max_depth, unsigned long long* __restrict__ counters)
+{
+    const uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
+    bool alive = false;
+    if (slot < W.n_slots) {
+        const uint32_t k = slot / W.n_pixels;
+        const uint32_t s = s_begin + k;
+        W.sum[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s < s_end && max_depth > 0) {
+            float4 o4, d4, a4, e4;
+            wf_start_sample<F>(S, W, slot, s, Wd, Hd, k0, k1, o4, d4, a4, e4);
+            W.ray_o[slot] = o4; W.ray_d[slot] = d4; W.att[slot] = a4; W.emi[slot] = e4;
+            alive = true;
+        }
+    }
+    wf_push(W.queue[0], &W.count[0], alive, slot);
+    /* samples counter: every sample of the range is rendered (black when max_depth is 0) */
+    if (slot == 0) atomicAdd(&counters[1], (unsigned long long)W.n_pixels * (unsigned long long)(s_end - s_begin));
+}
+
+template <uint32_t F, int BG>
+__global__ __launch_bounds__(RT_BLOCK) void wf_logic_kernel(DScene S, WfState W, int qi, int Wd, int Hd, uint32_t s_end,
+                                                            uint32_t k0, uint32_t k1, int max_depth)
+{
+    __shared__ int slot_mem[RT_BLOCK];
+    int* slots = slot_mem + (threadIdx.x & ~63u);
+    const uint32_t n_queue = W.count[qi];
+    const uint32_t e = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (blockIdx.x * RT_BLOCK >= n_queue) return;             /* whole block beyond the queue */
+    const bool active = e < n_queue;
+    const uint32_t slot = active ? W.queue[qi][e] : 0u;
+
+    DRay ray = {mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f), 0.f};
+    V3 att = mk(1.f, 1.f, 1.f), emi = mk(0.f, 0.f, 0.f);
+    HitLite hl = {FLT_MAX, -1, -1, 0};
+    uint32_t sample = 0;
+    int depth = 0;
+    PathRng g;
+    rng_start(g, k0, k1, 0u, 0u);
+    if (active) {
+        const float4 o = W.ray_o[slot], d = W.ray_d[slot], a = W.att[slot], em = W.emi[slot], h = W.hit[slot];
+        ray.o = mk(o.x, o.y, o.z); ray.time = o.w; ray.d = mk(d.x, d.y, d.z);
+        depth = (int)__float_as_uint(d.w);
+        att = mk(a.x, a.y, a.z); sample = __float_as_uint(a.w);
+        emi = mk(em.x, em.y, em.z);
+        hl.t = h.x; hl.obj = __float_as_int(h.y); hl.grp = __float_as_int(h.z); hl.aux = __float_as_int(h.w);
+        rng_start(g, k0, k1, slot % W.n_pixels, sample);
+    }
+    /* one iteration of colour() / colourUnlit(), main.cu:53-70 / :77-98 — same body as render_kernel */
+    const bool hit = active && hl.obj >= 0;
+    HitRec rec;
+    rec.t = 0.f; rec.u = 0.f; rec.v = 0.f; rec.p = mk(0.f, 0.f, 0.f); rec.n = mk(0.f, 0.f, 0.f);
+    rec.material = 0; rec.prim_id = -1; rec.front = 0;
+    int mtype = RT_MAT_LIGHT;
+    if (hit) {
+        rebuild<F, false>(S, ray, hl, .001f, rec);
+        mtype = S.mats[rec.material].type;
+    }
+    const bool need_ball = hit && mtype != RT_MAT_LIGHT && mtype != RT_MAT_GLASS;
+    const V3 ball = random_in_unit_sphere_wave(g, (uint32_t)depth, need_ball, slots);
+    bool alive = false;
+    if (active) {
+        V3 result = mk(0.f, 0.f, 0.f);
+        bool done;
+        if (hit) {
+            V3 attenuation, emitted;
+            DRay scattered;
+            if (scatter<F>(S, ray, rec, g, (uint32_t)depth, ball, attenuation, scattered, emitted)) {
+                att = att * attenuation;
+                if (BG == RT_BG_BLACK) emi = emi + emitted * att;
+                ray = scattered;
+                done = false;
+            } else {
+                result = BG == RT_BG_BLACK ? emi + emitted * att : mk(0.f, 0.f, 0.f);
+                done = true;
+            }
+        } else {
+            if (BG == RT_BG_BLACK) result = emi;
+            else {
+                V3 ud = unit(ray.d);
+                float t = .5f * (ud.y + 1.f);
+                V3 c = (1.f - t) * mk(1.f, 1.f, 1.f) + t * mk(.5f, .7f, 1.f);
+                result = att * c;
+            }
+            done = true;
+        }
+        ++depth;
+        if (!done && depth >= max_depth) {
+            result = BG == RT_BG_BLACK ? emi : mk(0.f, 0.f, 0.f);
+            done = true;
+        }
+        if (!done) {
+            W.ray_o[slot] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.time);
+            W.ray_d[slot] = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float((uint32_t)depth));
+            W.att[slot] = make_float4(att.x, att.y, att.z, __uint_as_float(sample));
+            W.emi[slot] = make_float4(emi.x, emi.y, emi.z, 0.f);
+            alive = true;
+        } else {
+            float4 sm = W.sum[slot];
+            sm.x += result.x; sm.y += result.y; sm.z += result.z;
+            W.sum[slot] = sm;
+            const uint32_t next = sample + W.streams;
+            if (next < s_end && next > sample) {
+                float4 o4, d4, a4, e4;
+                wf_start_sample<F>(S, W, slot, next, Wd, Hd, k0, k1, o4, d4, a4, e4);
+                W.ray_o[slot] = o4; W.ray_d[slot] = d4; W.att[slot] = a4; W.emi[slot] = e4;
+                alive = true;
+            }
+        }
+    }
+    wf_push(W.queue[qi ^ 1], &W.count[qi ^ 1], alive, slot);
+}
+
+/* accum[pixel] += the K stream sums of the pixel, in stream order */
+__global__ __launch_bounds__(RT_BLOCK) void wf_finalize_kernel(WfState W, float* __restrict__ accum)
+{
+    const uint32_t p = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (p >= W.n_pixels) return;
+    float x = 0.f, y = 0.f, z = 0.f;
+    for (uint32_t k = 0; k < W.streams; ++k) {
+        const float4 s = W.sum[(size_t)k * W.n_pixels + p];
+        x += s.x; y += s.y; z += s.z;
+    }
+    float* a = accum + 3 * (size_t)p;
+    a[0] += x; a[1] += y; a[2] += z;
+}
+
+#endif

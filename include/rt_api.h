@@ -100,6 +100,17 @@ int  rt_trace_primary(rt_ctx* c, int width, int height, float s_off, float t_off
  * context's stream. */
 int  rt_render_accumulate(rt_ctx* c, int width, int height, uint32_t sample_begin, uint32_t sample_end,
                           uint64_t seed, int max_depth, int background, float* accum_dev);
+/* Which form of the integrator rt_render_accumulate runs (no counterpart in the reference, whose render
+ * kernel is one monolithic per-pixel loop, main.cu:125-198):
+ *   RT_INTEGRATOR_MEGAKERNEL  one kernel, a path stays in its lane from camera to termination and the lane
+ *                             starts its pixel's next sample the moment the path ends; asynchronous.
+ *   RT_INTEGRATOR_WAVEFRONT   path state in HBM, a persistent intersect kernel fed from a ray queue and a
+ *                             shading kernel alternate until every path has ended; the call returns after
+ *                             the last launch has been queued but blocks the host while the loop runs.
+ *   RT_INTEGRATOR_AUTO        (default) wavefront for scenes with a BVH, megakernel otherwise.
+ * Both trace the same path for the same (seed, pixel, sample). */
+enum rt_integrator { RT_INTEGRATOR_AUTO = 0, RT_INTEGRATOR_MEGAKERNEL = 1, RT_INTEGRATOR_WAVEFRONT = 2 };
+int  rt_ctx_set_integrator(rt_ctx* c, int mode);
 /* rgb_dev = gamma ? sqrtf(accum/spp) : accum/spp   (main.cu:192-196).  Asynchronous. */
 int  rt_resolve(rt_ctx* c, const float* accum_dev, int width, int height, uint32_t spp, int gamma,
                 float* rgb_dev);

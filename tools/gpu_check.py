@@ -9,6 +9,7 @@ O = load('rto', os.path.join(ROOT, 'oracle/oracle.py'))
 import torch
 orc = O.Oracle()
 ctx = B.Context(0)
+ctx.set_integrator(int(os.environ.get('RT_INTEGRATOR', '0')))
 rng = np.random.default_rng(1)
 names = sys.argv[1:] or ["cornell", "kat", "random_spheres", "lit_sphere", "bvh_boxes", "cornell_cluster", "final", "cornell_smoke"]
 for name in names:
