@@ -28,6 +28,12 @@
 #define RT_V_PLANAR_MEDIA (RT_F_PLANAR | RT_F_XFORM | RT_F_MEDIA | RT_F_ISO)           /* Cornell smoke */
 #define RT_V_LIST         (RT_F_ALL & ~RT_F_BVH)                                       /* any scene without a BVH */
 #define RT_V_BVH_TRI      (RT_F_BVH | RT_F_TRI | RT_F_PLANAR)                          /* triangle mesh + area light */
+#ifndef RT_WF_AUTO_ITEMS
+#define RT_WF_AUTO_ITEMS 65536
+#endif
+#ifndef RT_WF_SLOTS
+#define RT_WF_SLOTS (1u << 23)
+#endif
 #define RT_N_COUNTERS 16        /* rays, samples, then diagnostic slots */
 #ifndef RT_RENDER_WAVES_BVH
 #define RT_RENDER_WAVES_BVH 3  /* BVH variants: <=168 VGPRs, no spills */
@@ -258,6 +264,7 @@ struct rt_ctx {
     bool own_stream = false;
     bool have_scene = false;
     bool has_bvh = false;
+    int n_bvh_items = 0;
     uint32_t features = 0;    /* RT_F_* of the uploaded scene */
     int integrator = RT_INTEGRATOR_AUTO;
     /* wavefront path state (rt_wavefront.h), allocated on first use and kept */
@@ -388,6 +395,7 @@ extern "C" int rt_scene_upload(rt_ctx* c, const rt_flat_scene* s)
     c->ds.n_media = s->n_media;
     c->ds.cam = s->camera;
     c->has_bvh = s->n_bvh_nodes > 0;
+    c->n_bvh_items = s->n_bvh_items;
     c->stack_depth = stack_depth < 1 ? 1 : stack_depth;
     c->have_scene = true;
     return RT_OK;
@@ -465,8 +473,9 @@ static int wf_run(rt_ctx* c, int w, int h, uint32_t s0, uint32_t s1, uint32_t k0
                   int background, float* accum)
 {
     const uint32_t n_pixels = (uint32_t)w * (uint32_t)h;
-    /* about a million paths in flight: K sample streams per pixel, never more than there are samples */
-    uint32_t streams = ((1u << 20) + n_pixels - 1) / n_pixels;
+    /* about RT_WF_SLOTS paths in flight (each persistent lane should see many rays per launch, so that the
+     * drain at the end of a launch, when the queue is empty and waves wait for their last rays, stays small): K sample streams per pixel, never more than there are samples */
+    uint32_t streams = (RT_WF_SLOTS + n_pixels - 1) / n_pixels;
     if (streams > s1 - s0) streams = s1 - s0;
     if (streams < 1) streams = 1;
     const size_t n_slots = (size_t)n_pixels * streams;
@@ -528,7 +537,9 @@ extern "C" int rt_render_accumulate(rt_ctx* c, int w, int h, uint32_t s0, uint32
     dim3 grid(n_tiles(w, h));
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     HIPCHK(hipEventRecord(e0, c->stream));
-    const bool wavefront = c->integrator == RT_INTEGRATOR_WAVEFRONT || (c->integrator == RT_INTEGRATOR_AUTO && c->has_bvh);
+    /* auto: the wavefront form pays off once traversal dominates (measured: 2.2x on the 1M-triangle scene,
+     * 0.8x on the final scene with its 11k BVH items and media in the world list) */
+    const bool wavefront = c->integrator == RT_INTEGRATOR_WAVEFRONT || (c->integrator == RT_INTEGRATOR_AUTO && c->n_bvh_items >= RT_WF_AUTO_ITEMS);
     if (wavefront) {
         int wrc = (c->features & ~RT_V_BVH_TRI) == 0 ? wf_run<RT_V_BVH_TRI>(c, w, h, s0, s1, k0, k1, max_depth, background, accum)
                                                      : wf_run<RT_F_ALL>(c, w, h, s0, s1, k0, k1, max_depth, background, accum);

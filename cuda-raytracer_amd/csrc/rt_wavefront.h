@@ -39,6 +39,12 @@ struct WfState {
 };
 
 enum { WF_NEED = 0, WF_SCAN = 1, WF_BVH = 2 };
+#ifndef WF_PRIM_BATCH
+#define WF_CHUNK 256         /* queue entries a wave claims per atomic */
+#define WF_PRIM_BATCH 20     /* lanes at a leaf that make a primitive step worth running */
+#define WF_SCAN_BATCH 16     /* lanes at a scan record */
+#define WF_NODE_LOW 16       /* fewer interior lanes than this: run whatever else is waiting */
+#endif
 
 /* ------------------------------------------------------------------ intersect -- */
 template <uint32_t F>
@@ -66,20 +72,39 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_intersect_kernel(DScene S, WfStat
     uint32_t bounce = 0;
     uint32_t n_rays = 0;
     bool drained = false;                       /* wave-uniform: the queue has nothing left */
+    uint32_t chunk_next = 0, chunk_end = 0;     /* wave-uniform: this wave's claimed part of the queue */
+    /* chunk size: about half of a wave's fair share of the queue, so that short queues still spread over
+     * the whole grid, within [16, WF_CHUNK] */
+    uint32_t chunk = n_queue / (gridDim.x * (RT_BLOCK / 64) * 2u);
+    chunk = chunk < 16u ? 16u : (chunk > (uint32_t)WF_CHUNK ? (uint32_t)WF_CHUNK : chunk);
+#ifdef RT_STAMPS
+    unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* trips, busy lanes, node, prim, scan lanes, trips with scan, with prim, cycles */
+    const unsigned long long dg_t0 = __builtin_amdgcn_s_memtime();
+#endif
 
     while (true) {
         /* ---- refill: lanes without a ray take the next queue entries, a wave-wide batch at a time ---- */
         const unsigned long long need = __ballot(mode == WF_NEED);
         const int n_need = __popcll(need);
         if (!drained && (n_need >= 16 || n_need == 64)) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&W.count[2], (uint32_t)n_need);
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (base + (uint32_t)n_need >= n_queue) drained = true;
+            /* The wave owns a chunk [chunk_next, chunk_end) of the queue and hands its entries to idle
+             * lanes; one returning atomic on the shared head per WF_CHUNK rays (a single word sustains
+             * ~90 M dequeues/s on this chip, far below the ray rate if every refill paid one). */
+            if (chunk_next >= chunk_end) {
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(&W.count[2], chunk);
+                chunk_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                chunk_end = chunk_next + chunk < n_queue ? chunk_next + chunk : n_queue;
+                if (chunk_next >= n_queue) { drained = true; chunk_next = chunk_end = n_queue; }
+            }
+            const uint32_t base = chunk_next;
+            const uint32_t avail = chunk_end - chunk_next;
+            chunk_next += (uint32_t)n_need < avail ? (uint32_t)n_need : avail;
+            const uint32_t n_queue_w = chunk_end;     /* entries at or past the chunk's end wait for the next refill */
             if (mode == WF_NEED) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
                 const uint32_t e = base + rank;
-                if (e < n_queue) {
+                if (e < n_queue_w) {
                     slot = queue[e];
                     const float4 o = W.ray_o[slot], d = W.ray_d[slot];
                     rw.o = mk(o.x, o.y, o.z); rw.time = o.w;
@@ -105,18 +130,35 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_intersect_kernel(DScene S, WfStat
             continue;                            /* fewer than 16 idle lanes cannot happen here: all 64 are idle */
         }
 
-        /* ---- one step: every busy lane fetches the 64 bytes its step reads ---- */
+        /* ---- one step ----
+         * The three kinds of step cost very differently (a node ~60 VALU instructions, a triangle ~130, a
+         * scan record ~50-100) and a trip pays for every kind any lane runs.  A kind with few takers is
+         * therefore put off until enough lanes want it, or until the cheaper kinds have run dry: its lanes
+         * sit out a trip or two, and the wave stops paying a triangle test for two or three lanes. */
         const bool in_bvh = mode == WF_BVH;
         const bool interior = in_bvh && ref >= 0;
+        const bool at_leaf = in_bvh && ref < 0;
+        const bool in_scan = mode == WF_SCAN;
+        const int n_node = __popcll(__ballot(interior)), n_prim = __popcll(__ballot(at_leaf)), n_scan = __popcll(__ballot(in_scan));
+        const bool do_prim = n_prim >= WF_PRIM_BATCH || (n_prim > 0 && n_node < WF_NODE_LOW);
+        const bool do_scan = n_scan >= WF_SCAN_BATCH || (n_scan > 0 && n_node < WF_NODE_LOW && !do_prim) || (n_scan > 0 && n_node + n_prim == 0);
+        const bool step = interior || (at_leaf && do_prim) || (in_scan && do_scan);
+#ifdef RT_STAMPS
+        {
+            const int nb = __popcll(__ballot(mode != WF_NEED));
+            dg[0] += 1; dg[1] += nb; dg[2] += n_node; dg[3] += do_prim ? n_prim : 0; dg[4] += do_scan ? n_scan : 0; dg[5] += do_scan ? 1 : 0; dg[6] += do_prim ? 1 : 0;
+        }
+#endif
         const int lfirst = (~ref) >> 4, lcount = ((~ref) & 15) + 1;
         const float4* src = reinterpret_cast<const float4*>(S.prog);
-        if (mode == WF_SCAN) src = reinterpret_cast<const float4*>(S.prog + pc);
+        if (in_scan) src = reinterpret_cast<const float4*>(S.prog + pc);
         if (in_bvh) src = interior ? reinterpret_cast<const float4*>(S.nodes + ref)
                                    : reinterpret_cast<const float4*>(S.leafs + (lfirst + li));
         float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0, q3 = q0;
-        if (mode != WF_NEED) { q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3]; }
-
-        if (in_bvh) {
+        if (step) { q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3]; }
+        if (!step) {
+            /* this lane's kind of step was put off */
+        } else if (in_bvh) {
             if (interior) {
                 const float lmin[3] = {q0.x, q0.y, q0.z}, lmax[3] = {q0.w, q1.x, q1.y};
                 const float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
@@ -151,7 +193,7 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_intersect_kernel(DScene S, WfStat
                 }
             }
             if (ref == RT_REF_NONE) { mode = WF_SCAN; ++pc; }     /* the group is done: on with the world list */
-        } else if (mode == WF_SCAN) {
+        } else {
             const uint32_t head = __float_as_uint(q0.x);
             const int kind = (int)(head & 0xffu);
             const int obj = __float_as_int(q0.y);
@@ -206,6 +248,10 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_intersect_kernel(DScene S, WfStat
     unsigned long long r = n_rays;
     for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off);
     if (lane == 0) atomicAdd(&counters[0], r);
+#ifdef RT_STAMPS
+    dg[7] = __builtin_amdgcn_s_memtime() - dg_t0;
+    if (lane == 0) for (int q = 0; q < 8; ++q) atomicAdd(&counters[4 + q], dg[q]);
+#endif
 }
 
 /* ---------------------------------------------------------------------- logic -- */

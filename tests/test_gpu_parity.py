@@ -95,12 +95,21 @@ def test_closest_hit_matches_oracle_on_many_rays(binding, oracle, gpu_ctx, name,
     compare_hits(gpu_trace(gpu_ctx, allr, 0.5 * tm, 1.5 * tm), exp, types, name + " window", ties_ok=True)
 
 
-def render_gpu(ctx, binding, sc, W, H, s0, s1, seed, depth=100, bg=None):
+INTEGRATORS = ["megakernel", "wavefront"]
+
+
+def render_gpu(ctx, binding, sc, W, H, s0, s1, seed, depth=100, bg=None, integrator="auto"):
+    """integrator: which form of the path tracer runs (include/rt_api.h rt_ctx_set_integrator); both must trace
+    the same path for the same (seed, pixel, sample)"""
     import torch
     acc = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
-    ctx.render_accumulate(acc, W, H, s0, s1, seed, depth, sc.background if bg is None else bg)
-    ctx.synchronize()
+    ctx.set_integrator({"auto": 0, "megakernel": 1, "wavefront": 2}[integrator])
+    try:
+        ctx.render_accumulate(acc, W, H, s0, s1, seed, depth, sc.background if bg is None else bg)
+        ctx.synchronize()
+    finally:
+        ctx.set_integrator(0)
     return acc
 
 
@@ -109,13 +118,14 @@ def render_gpu(ctx, binding, sc, W, H, s0, s1, seed, depth=100, bg=None):
                                                ("lit_sphere", 0, 64, 48, 8), ("cornell_cluster", 0, 48, 32, 4),
                                                ("tri_mesh", 4000, 48, 32, 4), ("final", 8, 48, 32, 4),
                                                ("cornell", 0, 37, 23, 5)])
-def test_render_equals_oracle_sample_for_sample(binding, oracle, gpu_ctx, name, param, W, H, spp):
+@pytest.mark.parametrize("integrator", INTEGRATORS)
+def test_render_equals_oracle_sample_for_sample(binding, oracle, gpu_ctx, name, param, W, H, spp, integrator):
     """same (seed, pixel, sample) -> same path: the accumulation buffers agree pixel for pixel, up to the rare
     path whose branch hangs on a last-bit libm difference or an exact tie"""
     sc = binding.Scene(name, W, H, param)
     gpu_ctx.upload(sc)
     gpu_ctx.reset_counters()
-    got = render_gpu(gpu_ctx, binding, sc, W, H, 0, spp, 419).cpu().numpy().reshape(H, W, 3)
+    got = render_gpu(gpu_ctx, binding, sc, W, H, 0, spp, 419, integrator=integrator).cpu().numpy().reshape(H, W, 3)
     c = gpu_ctx.counters()
     exp, st = oracle.render(sc.flat, W, H, 0, spp, 419, 100, sc.background, threads=8)
     assert np.isfinite(got).all()
@@ -126,14 +136,15 @@ def test_render_equals_oracle_sample_for_sample(binding, oracle, gpu_ctx, name, 
     assert exp.sum() > 0
 
 
-def test_sky_integrator_and_depth_limit(binding, oracle, gpu_ctx):
+@pytest.mark.parametrize("integrator", INTEGRATORS)
+def test_sky_integrator_and_depth_limit(binding, oracle, gpu_ctx, integrator):
     """colourUnlit (main.cu:73-100) on a scene with emitters, and max_depth 0/1/3"""
     W, H = 48, 32
     sc = binding.Scene("kat", W, H)
     gpu_ctx.upload(sc)
     for bg in (binding.RT_BG_BLACK, binding.RT_BG_SKY):
         for depth in (0, 1, 3):
-            got = render_gpu(gpu_ctx, binding, sc, W, H, 0, 4, 7, depth, bg).cpu().numpy().reshape(H, W, 3)
+            got = render_gpu(gpu_ctx, binding, sc, W, H, 0, 4, 7, depth, bg, integrator=integrator).cpu().numpy().reshape(H, W, 3)
             exp, _ = oracle.render(sc.flat, W, H, 0, 4, 7, depth, bg, threads=4)
             bad = np.any(np.abs(got - exp) > 1e-4 * (1 + np.abs(exp)), axis=2)
             assert bad.mean() <= 0.005, (bg, depth, bad.sum())
@@ -192,11 +203,60 @@ def test_converged_image_rmse(binding, oracle_mod, gpu_ctx, name):
     assert oracle_mod.scene_digest(sc.flat) == str(g["digest"])
     gpu_ctx.upload(sc)
     spp = 4 * int(g["spp"])
-    acc = render_gpu(gpu_ctx, binding, sc, W, H, 0, spp, 99991)
+    # the wavefront form runs thousands of sample streams of the 64x64 frame side by side; the megakernel
+    # would occupy 16 workgroups for minutes.  test_integrators_agree ties the two together.
+    acc = render_gpu(gpu_ctx, binding, sc, W, H, 0, spp, 99991, integrator="wavefront")
     img = (acc.cpu().numpy().reshape(H, W, 3) / np.float32(spp))
     rmse = float(np.sqrt(np.mean((img - g["image"]) ** 2)))
     limit = 1e-3 if name in ("cornell", "cornell_smoke") else 4e-3   # goldens of the slow scenes have fewer spp
     assert rmse <= limit, rmse
+
+
+@pytest.mark.parametrize("name,param", [("cornell", 0), ("cornell_smoke", 0), ("final", 8), ("tri_mesh", 20000)])
+def test_integrators_agree(binding, gpu_ctx, name, param):
+    """megakernel and wavefront render the same samples: images equal up to the order of the per-pixel sums"""
+    import torch
+    W, H, spp = 64, 64, 48
+    sc = binding.Scene(name, W, H, param)
+    gpu_ctx.upload(sc)
+    gpu_ctx.reset_counters()
+    a = render_gpu(gpu_ctx, binding, sc, W, H, 3, 3 + spp, 77, integrator="megakernel")
+    ca = gpu_ctx.counters()
+    gpu_ctx.reset_counters()
+    b = render_gpu(gpu_ctx, binding, sc, W, H, 3, 3 + spp, 77, integrator="wavefront")
+    cb = gpu_ctx.counters()
+    assert (ca.rays, ca.samples) == (cb.rays, cb.samples)
+    assert torch.allclose(a, b, rtol=2e-5, atol=1e-5)
+    b2 = render_gpu(gpu_ctx, binding, sc, W, H, 3, 3 + spp, 77, integrator="wavefront")
+    assert torch.equal(b, b2), "the wavefront image is not reproducible"
+
+
+def test_wavefront_at_full_size(binding, gpu_ctx):
+    """BASELINE.json config 4 shape (1920x1080, 1M triangles), few samples: finite, deterministic, additive over
+    sample ranges, ray count equal to the megakernel's"""
+    import torch
+    W, H = 1920, 1080
+    sc = binding.Scene("tri_mesh", W, H, 1000000)
+    gpu_ctx.upload(sc)
+    gpu_ctx.reset_counters()
+    a = render_gpu(gpu_ctx, binding, sc, W, H, 0, 4, 9, integrator="wavefront")
+    ca = gpu_ctx.counters()
+    assert torch.isfinite(a).all() and float(a.sum()) > 0
+    assert ca.samples == W * H * 4
+    b = render_gpu(gpu_ctx, binding, sc, W, H, 0, 2, 9, integrator="wavefront")
+    gpu_ctx.set_integrator(2)
+    gpu_ctx.render_accumulate(b, W, H, 2, 4, 9, 100, sc.background)
+    gpu_ctx.synchronize()
+    gpu_ctx.set_integrator(0)
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    gpu_ctx.reset_counters()
+    m = render_gpu(gpu_ctx, binding, sc, W, H, 0, 1, 9, integrator="megakernel")
+    cm = gpu_ctx.counters()
+    gpu_ctx.reset_counters()
+    w1 = render_gpu(gpu_ctx, binding, sc, W, H, 0, 1, 9, integrator="wavefront")
+    cw = gpu_ctx.counters()
+    assert cm.rays == cw.rays
+    assert torch.equal(m, w1)          # one stream per pixel: same summation order, same bits
 
 
 def test_full_size_properties(binding, gpu_ctx):
@@ -236,7 +296,9 @@ def test_edge_cases(binding, gpu_ctx):
     with pytest.raises(binding.RtError):
         gpu_ctx.render_accumulate(acc, W, H, 6, 5, 1, 100, 0)
     with pytest.raises(binding.RtError):
-        gpu_ctx.render_accumulate(acc, W, H, 0, 1, 1, 100, 7)      # no such integrator
+        gpu_ctx.render_accumulate(acc, W, H, 0, 1, 1, 100, 7)      # no such background
+    with pytest.raises(binding.RtError):
+        gpu_ctx.set_integrator(5)
     empty = torch.zeros((0, 7), dtype=torch.float32, device="cuda")
     assert len(gpu_ctx.trace_rays(empty, 0.001, 1.0)) == 0
     fresh = binding.Context(0)
