@@ -46,14 +46,18 @@ def flops_per_ray(st):
     return f + F_SHADE
 
 
-def bytes_per_ray(st, width, height, spp, scene_bytes):
-    """algorithmic HBM bytes per ray of the register-resident integrator: BVH nodes (32 B) and BVH-leaf
-    primitives (128 B rows) fetched per ray, plus the accumulation buffer read+write (24 B/pixel per
-    launch) and one read of the scene tables, amortised over the launch's rays."""
+def bytes_per_ray(st, width, height, spp, scene_bytes, wavefront=False):
+    """algorithmic bytes per ray: 32 B per BVH node box tested and 64 B per BVH-leaf primitive row
+    (counted by the instrumented CPU traversal of the same BVH), plus the accumulation buffer read+write
+    (24 B/pixel per launch) and one read of the scene tables amortised over the launch's rays; the wavefront
+    form adds its path-state traffic: ray 32 B written + read, hit 16 B written + read, attenuation / emission
+    32 B read + written = 160 B per ray."""
     rays = max(1, st.rays)
     per_ray = 32.0 * st.nodes_visited / rays
     if st.nodes_visited:
-        per_ray += 128.0 * st.prim_tests / rays
+        per_ray += 64.0 * st.prim_tests / rays
+    if wavefront:
+        per_ray += 160.0
     samples = max(1, st.samples)
     rays_per_launch = (rays / samples) * width * height * spp
     return per_ray + (24.0 * width * height + scene_bytes) / rays_per_launch
@@ -105,6 +109,7 @@ def main():
     ap.add_argument("--param", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--integrator", default="auto", choices=["auto", "megakernel", "wavefront"])
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary workload line of the default run")
     args = ap.parse_args()
 
     import torch
@@ -126,92 +131,109 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     b = entry.load_binding()
-    scene_name, param, W, H, spp = WORKLOADS[args.workload]
-    W, H, spp = args.width or W, args.height or H, args.spp or spp
-    if args.param >= 0:
-        param = args.param
-    scene = b.Scene(scene_name, W, H, param)
-    flat = scene.flat.contents
-    background = scene.background
-    has_bvh = flat.n_bvh_nodes > 0
-    scene_bytes = (flat.n_objects * 128 + flat.n_ops * 16 + flat.n_materials * 16 + flat.n_textures * 40
-                   + flat.n_image_bytes + flat.n_bvh_nodes * 32 + flat.n_bvh_items * 4)
 
-    stream = torch.cuda.current_stream(dev)
-    ctx = b.Context(local_rank, stream.cuda_stream)
-    ctx.upload(scene)
-    ctx.set_integrator({"auto": 0, "megakernel": 1, "wavefront": 2}[args.integrator])
-    accum = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
-    rgb = None
+    def run(workload, W, H, spp, param, steps, warmup, want_cpu):
+        """time `steps` renders of one workload; returns the result dict (rank 0) or None"""
+        scene_name, dparam, dW, dH, dspp = WORKLOADS[workload]
+        W, H, spp = W or dW, H or dH, spp or dspp
+        param = dparam if param < 0 else param
+        scene = b.Scene(scene_name, W, H, param)
+        flat = scene.flat.contents
+        background = scene.background
+        has_bvh = flat.n_bvh_nodes > 0
+        scene_bytes = (flat.n_objects * 128 + flat.n_ops * 16 + flat.n_materials * 16 + flat.n_textures * 40
+                       + flat.n_image_bytes + flat.n_bvh_nodes * 32 + flat.n_bvh_items * 64)
+        stream = torch.cuda.current_stream(dev)
+        ctx = b.Context(local_rank, stream.cuda_stream)
+        ctx.upload(scene)
+        ctx.set_integrator({"auto": 0, "megakernel": 1, "wavefront": 2}[args.integrator])
+        wavefront = args.integrator == "wavefront" or (args.integrator == "auto" and flat.n_bvh_items >= 65536)
+        accum = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
+        rgb = None
 
-    def step(k):
-        nonlocal rgb
-        accum.zero_()
-        s0 = (k * world + rank) * spp            # every step and rank renders fresh sample indices
-        ctx.render_accumulate(accum, W, H, s0, s0 + spp, 419, 100, background)
+        def step(k):
+            nonlocal rgb
+            accum.zero_()
+            s0 = (k * world + rank) * spp            # every step and rank renders fresh sample indices
+            ctx.render_accumulate(accum, W, H, s0, s0 + spp, 419, 100, background)
+            if world > 1:
+                dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                rgb = ctx.resolve(accum, W, H, spp * world, gamma=True)
+
+        def fence():
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+
+        for k in range(warmup):
+            step(k)
+        fence()
+        ctx.reset_counters()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(warmup + k)
+        fence()
+        dt = time.perf_counter() - t0
+        c = ctx.counters()
+
+        tot = torch.tensor([float(c.rays), float(c.samples)], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt, c.render_ms / max(1, c.render_launches)], dtype=torch.float64, device=dev)
         if world > 1:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
-        if rank == 0:
-            rgb = ctx.resolve(accum, W, H, spp * world, gamma=True)
-
-    def fence():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for k in range(args.warmup):
-        step(k)
-    fence()
-    ctx.reset_counters()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k)
-    fence()
-    dt = time.perf_counter() - t0
-    c = ctx.counters()
-
-    tot = torch.tensor([float(c.rays), float(c.samples)], dtype=torch.float64, device=dev)
-    tmax = torch.tensor([dt, c.render_ms / max(1, c.render_launches)], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    rays, samples = tot.tolist()
-    dt, kernel_ms = tmax.tolist()
-
-    if rank == 0:
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        rays, samples = tot.tolist()
+        dt, kernel_ms = tmax.tolist()
+        ctx.close()
+        if rank != 0:
+            return None
         finite = bool(torch.isfinite(rgb).all().item())
         mean_rgb = float(rgb.mean().item())
         out = {
             "metric": "Mrays/s", "value": rays / dt / 1e6, "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s_%dx%d_%dspp" % (args.workload, W, H, spp), "scene": scene_name,
+            "config": {"workload": "%s_%dx%d_%dspp" % (workload, W, H, spp), "scene": scene_name,
                        "width": W, "height": H, "spp_per_gpu": spp, "max_depth": 100,
                        "background": "sky" if background else "black", "bvh": has_bvh,
+                       "integrator": "wavefront" if wavefront else "megakernel",
                        "parallelism": "spp-shard x%d + RCCL reduce" % world if world > 1 else "single GPU"},
             "samples_per_s": samples / dt, "rays_per_sample": rays / max(1.0, samples),
             "image_mean": mean_rgb, "image_finite": finite,
         }
         base_stats = None
-        if not args.no_cpu_baseline and world == 1:
-            o = entry.load_oracle()
+        o = entry.load_oracle() if world == 1 and not args.no_cpu_baseline else None
+        if o is not None and want_cpu:
             out["cpu_baseline"], base_stats = cpu_baseline(b, o, scene_name, param, background, has_bvh)
-        elif world == 1:
+        elif o is not None:
+            # no timed baseline for this line: a short instrumented oracle pass only counts the algorithmic work
+            small = b.Scene(scene_name, 128, 72, param)
+            _, base_stats = o.Oracle().render(small.flat, 128, 72, 0, 2, 419, 100, background, use_bvh=has_bvh, threads=16)
             out["cpu_baseline"] = None
-        # roofline of the dominant kernel (render_kernel), duration from HIP events on its own stream
+        else:
+            out["cpu_baseline"] = None
+        # roofline of the dominant kernel, duration from HIP events recorded on its own stream inside the library.
+        # megakernel: render_kernel is the launch; wavefront: the event pair spans the whole intersect/logic loop
+        # (profiles/ has the per-kernel split: wf_intersect is ~85 % of it).
         rays_per_launch = rays / world / max(1, c.render_launches)
-        roof = {"bound": "valu", "kernel": "render_kernel", "kernel_ms": kernel_ms, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
-                "achieved": None, "frac": None, "traffic": None,
-                "hbm_peak_GBs": PEAK_HBM_GBS, "hbm_achieved_GBs": None, "hbm_frac": None}
+        kname = "wf_intersect_kernel + wf_logic_kernel loop" if wavefront else "render_kernel"
+        roof = {"bound": "hbm" if wavefront else "valu", "kernel": kname, "kernel_ms": kernel_ms,
+                "peak": PEAK_HBM_GBS if wavefront else PEAK_VALU_TFLOPS, "unit": "GB/s" if wavefront else "TFLOP/s",
+                "achieved": None, "frac": None, "traffic": None}
         if base_stats is not None and kernel_ms > 0:
             fpr = flops_per_ray(base_stats)
-            bpr = bytes_per_ray(base_stats, W, H, spp, scene_bytes)
-            ach = rays_per_launch * fpr / (kernel_ms * 1e-3) / 1e12
-            hb = rays_per_launch * bpr / (kernel_ms * 1e-3) / 1e9
-            roof.update({"achieved": ach, "frac": ach / PEAK_VALU_TFLOPS, "flops_per_ray": fpr, "bytes_per_ray": bpr,
-                         "hbm_achieved_GBs": hb, "hbm_frac": hb / PEAK_HBM_GBS})
+            bpr = bytes_per_ray(base_stats, W, H, spp, scene_bytes, wavefront)
+            ach_f = rays_per_launch * fpr / (kernel_ms * 1e-3) / 1e12
+            ach_b = rays_per_launch * bpr / (kernel_ms * 1e-3) / 1e9
+            if wavefront:
+                roof.update({"achieved": ach_b, "frac": ach_b / PEAK_HBM_GBS})
+            else:
+                roof.update({"achieved": ach_f, "frac": ach_f / PEAK_VALU_TFLOPS})
+            roof.update({"flops_per_ray": fpr, "bytes_per_ray": bpr,
+                         "valu_peak_TFLOPs": PEAK_VALU_TFLOPS, "valu_achieved_TFLOPs": ach_f, "valu_frac": ach_f / PEAK_VALU_TFLOPS,
+                         "hbm_peak_GBs": PEAK_HBM_GBS, "hbm_achieved_GBs": ach_b, "hbm_frac": ach_b / PEAK_HBM_GBS})
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
@@ -219,6 +241,15 @@ def main():
             except Exception:
                 pass
         out["roofline"] = roof
+        return out
+
+    out = run(args.workload, args.width, args.height, args.spp, args.param, args.steps, args.warmup, True)
+    if rank == 0:
+        if world == 1 and args.workload == "cornell" and not args.no_extras:
+            # the north_star target scene beside the headline one: BASELINE.json configs[3] at reduced spp
+            # (the full 256 spp take ~1.3 s per step; the rate is the same from ~32 spp up)
+            extra = run("tri_mesh", 0, 0, 32, -1, 1, 1, False)
+            out["also"] = [{k: extra[k] for k in ("value", "unit", "ms_per_step", "config", "samples_per_s", "rays_per_sample", "roofline")}]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

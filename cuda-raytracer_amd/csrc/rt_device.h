@@ -458,6 +458,12 @@ __device__ __forceinline__ HitLite closest_hit(const DScene& S, const DRay& r, f
                 else h = rect_t<0>(cur.v1, cur.v2, cur.v3, cur.v4, cur.v0, rl, tMin, best.t, t);
                 if (h) { best.t = t; best.obj = cur.obj; best.grp = -1; best.aux = (int)((cur.head >> 16) & 0xffu); }
             }
+        } else if (kind == RT_P_BOX) {
+            if (F & RT_F_PLANAR) {
+                const float f[6] = {cur.v0, cur.v1, cur.v2, cur.v3, cur.v4, cur.v5};
+                float t; int face;
+                if (box_t(f, rl, tMin, best.t, t, face)) { best.t = t; best.obj = cur.obj; best.grp = -1; best.aux = face; }
+            }
         } else if (kind == RT_P_XFORM) {
             if (F & RT_F_XFORM) {
                 rl = r;

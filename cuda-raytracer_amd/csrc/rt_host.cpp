@@ -231,17 +231,10 @@ void rt_pack_program(const rt_flat_scene* s, std::vector<DProg>& prog)
             for (int k = 0; k < 4; ++k) r.v[k] = f[k];
             prog.push_back(r);
         } else if (o.type == RT_OBJ_BOX) {
-            /* Box.cuh:24-36: z = p1.z, z = p0.z, y = p1.y, y = p0.y, x = p1.x, x = p0.x */
-            const int   axis[6] = {2, 2, 1, 1, 0, 0};
-            const float k6[6]   = {f[5], f[2], f[4], f[1], f[3], f[0]};
-            for (int face = 0; face < 6; ++face) {
-                const int ka = axis[face];
-                r.head = RT_P_RECT | ((uint32_t)ka << 8) | ((uint32_t)face << 16);
-                r.v[0] = k6[face];
-                r.v[1] = ka == 0 ? f[1] : f[0]; r.v[2] = ka == 0 ? f[4] : f[3];
-                r.v[3] = ka == 2 ? f[1] : f[2]; r.v[4] = ka == 2 ? f[4] : f[5];
-                prog.push_back(r);
-            }
+            /* one record, six faces tested in the order of Box.cuh:24-36 by straight-line code */
+            r.head = RT_P_BOX;
+            for (int k = 0; k < 6; ++k) r.v[k] = f[k];
+            prog.push_back(r);
         } else {
             const int ka = RT_OBJ_RECT_YZ - o.type;   /* XY -> 2, XZ -> 1, YZ -> 0 */
             r.head = RT_P_RECT | ((uint32_t)ka << 8);

@@ -38,15 +38,14 @@ struct alignas(16) DNode {
     int32_t pad[2];
 };
 /* The world list as a linear program of 32-byte records, read wave-uniformly (one s_load_dwordx8
- * each, the next one prefetched) by the closest-hit scan.  A Box is six RECT records in the order of
- * Box.cuh:24-36; consecutive objects under the same wrapper chain share one XFORM record; everything
+ * each, the next one prefetched) by the closest-hit scan.  Consecutive objects under the same wrapper chain share one XFORM record; everything
  * else (groups, media, moving spheres, triangles, chains longer than two) is a GENERIC record that
  * sends the scan through the object's row. */
-enum { RT_P_END = 0, RT_P_XFORM = 1, RT_P_RECT = 2, RT_P_SPHERE = 3, RT_P_GENERIC = 4 };
+enum { RT_P_END = 0, RT_P_XFORM = 1, RT_P_RECT = 2, RT_P_SPHERE = 3, RT_P_GENERIC = 4, RT_P_BOX = 5 };
 struct alignas(32) DProg {
     uint32_t head;   /* kind | XFORM: nops<<8 | op0 type<<16 | op1 type<<20 ; RECT: axis<<8 | face<<16 */
     int32_t  obj;    /* object index (RECT/SPHERE/GENERIC) */
-    float    v[6];   /* XFORM: op0 abc, op1 abc; RECT: k a0 a1 b0 b1; SPHERE: cx cy cz r */
+    float    v[6];   /* XFORM: op0 abc, op1 abc; RECT: k a0 a1 b0 b1; SPHERE: cx cy cz r; BOX: p0 xyz, p1 xyz */
 };
 
 /* scene feature bits: a render kernel is compiled for a set of them and leaves the rest out */

@@ -215,6 +215,13 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_intersect_kernel(DScene S, WfStat
                     }
                 }
                 ++pc;
+            } else if (kind == RT_P_BOX) {
+                if (F & RT_F_PLANAR) {
+                    const float f[6] = {q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                    float t; int face;
+                    if (box_t(f, rl, tMin, best.t, t, face)) { best.t = t; best.obj = obj; best.grp = -1; best.aux = face; }
+                }
+                ++pc;
             } else if (kind == RT_P_XFORM) {
                 if (F & RT_F_XFORM) {
                     rl = rw;

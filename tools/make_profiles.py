@@ -1,0 +1,47 @@
+"""Copy the rocprofv3 summaries of a tools/prof_round.sh run from gpurun_out/<tag>/ into profiles/ (tracked):
+kernel-trace stats, one text file of PMC sums per kernel, and profiles/hbm_traffic.json (bytes per render call,
+read by bench.py as roofline.traffic).  FETCH_SIZE / WRITE_SIZE are in KiB.  Corrections (MI355X_MICROARCH.md,
+HBM): the Cornell megakernel reads its accumulation buffer as a coalesced stream, for which gfx950 tallies half
+the bytes -> FETCH doubled; the wavefront kernels gather 64-byte rows, and there FETCH_SIZE agrees with
+TCC_MISS x 64 B (656 GB vs 618 GB), so it is taken as it stands."""
+import collections, csv, glob, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+def sums(d):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(os.path.join(src, d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            if not any(s in k for s in ("wf_", "render_kernel")):
+                continue
+            a = acc[(k, r["Counter_Name"])]
+            a[0] += float(r["Counter_Value"]); a[1] += 1
+    return acc
+
+for name in ("trace_default", "trace_tri"):
+    for f in glob.glob(os.path.join(src, name, "**", "*kernel_stats.csv"), recursive=True):
+        rows = list(csv.reader(open(f)))
+        keep = [rows[0]] + [r for r in rows[1:] if any(s in r[0] for s in ("wf_", "render_kernel", "resolve_kernel"))]
+        with open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, name)), "w", newline="") as o:
+            csv.writer(o, quoting=csv.QUOTE_ALL).writerows(keep)
+
+allsum = {}
+for wl, dirs in (("cornell", ["cornell_fetch", "cornell_write", "cornell_sq", "cornell_sq2"]),
+                 ("tri", ["tri_fetch", "tri_write", "tri_tcc", "tri_sq", "tri_grbm"])):
+    with open(os.path.join(dst, "%s_%s_pmc.txt" % (tag, wl)), "w") as o:
+        o.write("# rocprofv3 --pmc sums over all launches of one bench.py render call (tools/prof_round.sh); one pass per counter group\n")
+        for d in dirs:
+            a = sums(d)
+            for (k, c), (v, n) in sorted(a.items()):
+                o.write("%-34s %-24s sum=%.6g launches=%d\n" % (k[:34], c, v, n))
+                allsum[(wl, k.split("<")[0].replace("void ", ""), c)] = v
+traffic = {
+    "cornell_1024x1024_1024spp": (2.0 * allsum[("cornell", "render_kernel", "FETCH_SIZE")] + allsum[("cornell", "render_kernel", "WRITE_SIZE")]) * 1024.0,
+    "tri_mesh_1920x1080_32spp": sum(v for (wl, k, c), v in allsum.items() if wl == "tri" and c in ("FETCH_SIZE", "WRITE_SIZE")) * 1024.0,
+}
+json.dump(traffic, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+print(traffic)
