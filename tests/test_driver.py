@@ -1,0 +1,60 @@
+"""The reference's host program over the library (cuda-raytracer_amd/driver/rt_main.cpp): prompts, exit codes,
+output file, and the image it writes = the image the C ABI renders for the same seed and sample range."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+EXE = os.path.join(ROOT, "cuda-raytracer_amd", "rt_render")
+
+
+def run_driver(tmp_path, stdin, *argv):
+    return subprocess.run([EXE, *argv], input=stdin, capture_output=True, text=True, cwd=str(tmp_path), timeout=120)
+
+
+def read_ppm(path):
+    raw = open(path, "rb").read()
+    magic, dims, maxv, body = raw.split(b"\n", 3)
+    w, h = (int(v) for v in dims.split())
+    assert magic == b"P6" and maxv == b"255" and len(body) == w * h * 3
+    return np.frombuffer(body, np.uint8).reshape(h, w, 3)
+
+
+def test_driver_is_built():
+    assert os.path.exists(EXE), "build it with make -C cuda-raytracer_amd (or __graft_entry__.build())"
+
+
+@pytest.mark.gpu
+def test_prompts_and_image(binding, gpu_ctx, tmp_path):
+    import torch
+    W, H, spp = 64, 48, 8
+    r = run_driver(tmp_path, "%d\n%d\n%d\n1\n" % (W, H, spp))
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == "Width: Height: Number of Samples: # of GPUs: "          # main.cu:630-640
+    assert "Rendering a 64x48 image with 1 GPU" in r.stderr and "Rendered in" in r.stderr
+    img = read_ppm(tmp_path / "output" / "singleGPUTesting.ppm")
+    # the same render through the ABI: seed 419, samples [0, spp), depth 100, gamma 2, top row first
+    sc = binding.Scene("cornell", W, H)
+    gpu_ctx.upload(sc)
+    acc = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    gpu_ctx.render_accumulate(acc, W, H, 0, spp, 419, 100, sc.background)
+    rgb = gpu_ctx.resolve(acc, W, H, spp, gamma=True)
+    gpu_ctx.synchronize()
+    exp = np.clip((255.99 * rgb.cpu().numpy().astype(np.float64)).astype(np.int64), 0, 255).astype(np.uint8).reshape(H, W, 3)[::-1]
+    assert np.array_equal(img, exp)
+
+
+@pytest.mark.gpu
+def test_user_scene_and_bad_input(tmp_path):
+    r = run_driver(tmp_path, "48\n32\n4\n1\n", "user")
+    assert r.returncode == 0, r.stderr
+    img = read_ppm(tmp_path / "output" / "singleGPUTesting.ppm")
+    assert img.shape == (32, 48, 3) and img.max() > 0
+    r = run_driver(tmp_path, "0\n32\n4\n1\n")
+    assert r.returncode == 1
+    r = run_driver(tmp_path, "16\n16\n1\n1\n", "no_such_scene")
+    assert r.returncode == 99 and "unknown built-in scene" in r.stderr         # main.cu:33-44 exit code
