@@ -39,6 +39,7 @@ struct DScene {
     const rt_texture*  __restrict__ texs;
     const uint8_t*     __restrict__ image;
     const DNode*       __restrict__ nodes;   /* 64-byte two-box nodes (rt_host.h) */
+    const DNode4*      __restrict__ nodes4;  /* 128-byte four-box nodes of the same trees (wavefront) */
     const DObj*        __restrict__ leafs;   /* BVH leaf table: first 64 bytes of each row are read */
     const DProg*       __restrict__ prog;    /* the world list as 32-byte scan records (rt_host.h) */
     int32_t world;

@@ -186,6 +186,65 @@ bool rt_pack_bvh(const rt_flat_scene* s, std::vector<DObj>& objs, std::vector<DN
     return true;
 }
 
+void rt_pack_bvh4(const rt_flat_scene* s, std::vector<DObj>& objs, std::vector<DNode4>& nodes4, int* depth)
+{
+    nodes4.clear();
+    int deepest = 0;
+    auto area = [&](uint32_t ni) {
+        const rt_bvh_node& n = s->bvh_nodes[ni];
+        float e0 = n.bmax[0] - n.bmin[0], e1 = n.bmax[1] - n.bmin[1], e2 = n.bmax[2] - n.bmin[2];
+        return e0 * e1 + e1 * e2 + e2 * e0;
+    };
+    struct Todo { uint32_t abi; int node4; int level; };
+    for (int gi = 0; gi < s->n_objects; ++gi) {
+        const rt_object& g = s->objects[gi];
+        if (g.type != RT_OBJ_GROUP || g.bvh_root < 0) continue;
+        std::vector<Todo> todo;
+        auto child_ref = [&](uint32_t ni, int level) -> int32_t {
+            const rt_bvh_node& c = s->bvh_nodes[ni];
+            if (c.count) return ~(int32_t)((c.left_first << 4) | (c.count - 1));
+            int32_t id = (int32_t)nodes4.size();
+            nodes4.push_back(DNode4());
+            todo.push_back({ni, id, level});
+            return id;
+        };
+        objs[(size_t)gi].pad[0] = child_ref((uint32_t)g.bvh_root, 1);
+        while (!todo.empty()) {
+            Todo e = todo.back();
+            todo.pop_back();
+            if (e.level > deepest) deepest = e.level;
+            const rt_bvh_node& n = s->bvh_nodes[e.abi];
+            uint32_t cands[4] = {n.left_first, n.left_first + 1, 0, 0};
+            int nc = 2;
+            while (nc < 4) {
+                int pick = -1;
+                float best = -1.f;
+                for (int k = 0; k < nc; ++k)
+                    if (s->bvh_nodes[cands[k]].count == 0 && area(cands[k]) > best) { best = area(cands[k]); pick = k; }
+                if (pick < 0) break;
+                const uint32_t lf = s->bvh_nodes[cands[pick]].left_first;
+                cands[pick] = lf;
+                cands[nc++] = lf + 1;
+            }
+            int32_t refs[4];
+            for (int k = 0; k < nc; ++k) refs[k] = child_ref(cands[k], e.level + 1);
+            DNode4& d = nodes4[(size_t)e.node4];      /* taken after child_ref: it may grow the vector */
+            for (int k = 0; k < 4; ++k) {
+                if (k < nc) {
+                    const rt_bvh_node& c = s->bvh_nodes[cands[k]];
+                    for (int a = 0; a < 3; ++a) { d.box[k][a] = c.bmin[a]; d.box[k][3 + a] = c.bmax[a]; }
+                    d.ref[k] = refs[k];
+                } else {
+                    for (int a = 0; a < 3; ++a) { d.box[k][a] = 3.0e38f; d.box[k][3 + a] = -3.0e38f; }
+                    d.ref[k] = RT_REF_NONE;
+                }
+                d.pad[k] = 0;
+            }
+        }
+    }
+    if (depth) *depth = deepest;
+}
+
 void rt_pack_program(const rt_flat_scene* s, std::vector<DProg>& prog)
 {
     prog.clear();

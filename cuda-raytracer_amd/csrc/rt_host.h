@@ -68,6 +68,16 @@ enum {
     RT_F_ALL = (1u << 15) - 1
 };
 
+/* 4-wide node for the wavefront intersect kernel, 128 bytes: the boxes of up to four children (binary
+ * nodes collapsed by surface area on the host) and their references (same encoding as DNode; an unused
+ * slot is RT_REF_NONE with an inverted box).  Traversal there is bound by dependent fetches, and a 4-wide
+ * step does the work of two or three binary ones per round trip. */
+struct alignas(16) DNode4 {
+    float   box[4][6];   /* per child: min xyz, max xyz */
+    int32_t ref[4];
+    int32_t pad[4];
+};
+
 #define RT_REF_NONE ((int32_t)0x80000000)
 #define RT_MAX_LEAF 16
 #define RT_MAX_STACK 64
@@ -89,6 +99,10 @@ void rt_pack_objects(const rt_flat_scene* s, DObj* out);
 #include <vector>
 bool rt_pack_bvh(const rt_flat_scene* s, std::vector<DObj>& objs, std::vector<DNode>& nodes,
                  std::vector<DObj>& leafs_full, int* depth, std::string& why);
+
+/* the same trees collapsed to 4-wide nodes; each BVH group's root reference goes to DObj::pad[0].
+ * depth receives the deepest chain of DNode4s (a traversal needs at most 3 stack entries per level). */
+void rt_pack_bvh4(const rt_flat_scene* s, std::vector<DObj>& objs, std::vector<DNode4>& nodes4, int* depth);
 
 /* the world list -> program records (terminated by one RT_P_END record) */
 void rt_pack_program(const rt_flat_scene* s, std::vector<DProg>& prog);

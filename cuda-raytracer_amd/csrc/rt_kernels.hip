@@ -273,9 +273,10 @@ struct rt_ctx {
     size_t wf_slots_cap = 0;
     uint32_t* wf_host_count = nullptr;   /* pinned */
     int stack_depth = 0;      /* LDS stack entries per lane the uploaded BVHs need */
+    int stack4 = 1;           /* entries a traversal of the 4-wide trees can need (3 per level) */
     DScene ds;
     void* d_objs = nullptr;  void* d_ops = nullptr;   void* d_mats = nullptr; void* d_texs = nullptr;
-    void* d_image = nullptr; void* d_nodes = nullptr; void* d_leafs = nullptr; void* d_prog = nullptr;
+    void* d_image = nullptr; void* d_nodes = nullptr; void* d_leafs = nullptr; void* d_prog = nullptr; void* d_nodes4 = nullptr;
     unsigned long long* d_counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     /* render launches whose event pair has not been read back yet are timed lazily */
@@ -286,7 +287,7 @@ struct rt_ctx {
 
 static void free_scene(rt_ctx* c)
 {
-    void** ptrs[] = {&c->d_objs, &c->d_ops, &c->d_mats, &c->d_texs, &c->d_image, &c->d_nodes, &c->d_leafs, &c->d_prog};
+    void** ptrs[] = {&c->d_objs, &c->d_ops, &c->d_mats, &c->d_texs, &c->d_image, &c->d_nodes, &c->d_leafs, &c->d_prog, &c->d_nodes4};
     for (void** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
     c->have_scene = false;
 }
@@ -350,6 +351,9 @@ extern "C" int rt_scene_upload(rt_ctx* c, const rt_flat_scene* s)
     std::vector<DObj> leafs;
     int stack_depth = 0;
     if (!rt_pack_bvh(s, objs, nodes, leafs, &stack_depth, why)) { rt_set_error("rt_scene_upload: " + why); return RT_ERR_UNSUPPORTED; }
+    std::vector<DNode4> nodes4;
+    int depth4 = 0;
+    rt_pack_bvh4(s, objs, nodes4, &depth4);
     std::vector<DProg> prog;
     rt_pack_program(s, prog);
     if (stack_depth > RT_MAX_STACK) { rt_set_error("rt_scene_upload: BVH deeper than the traversal stack (64)"); return RT_ERR_UNSUPPORTED; }
@@ -381,7 +385,8 @@ extern "C" int rt_scene_upload(rt_ctx* c, const rt_flat_scene* s)
     if ((rc = upload(c, &c->d_nodes, nodes.data(), nodes.size()))) return rc;
     if ((rc = upload(c, &c->d_leafs, leafs.data(), leafs.size()))) return rc;
     if ((rc = upload(c, &c->d_prog, prog.data(), prog.size()))) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream)); /* objs, nodes, leafs, prog and mats are locals */
+    if ((rc = upload(c, &c->d_nodes4, nodes4.data(), nodes4.size()))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream)); /* objs, nodes, nodes4, leafs, prog and mats are locals */
     c->ds.objs = (const DObj*)c->d_objs;
     c->ds.ops = (const rt_xform_op*)c->d_ops;
     c->ds.mats = (const rt_material*)c->d_mats;
@@ -390,6 +395,8 @@ extern "C" int rt_scene_upload(rt_ctx* c, const rt_flat_scene* s)
     c->ds.nodes = (const DNode*)c->d_nodes;
     c->ds.leafs = (const DObj*)c->d_leafs;
     c->ds.prog = (const DProg*)c->d_prog;
+    c->ds.nodes4 = (const DNode4*)c->d_nodes4;
+    c->stack4 = 3 * depth4 + 1;
     c->features = rt_scene_features(s);
     c->ds.world = s->world;
     c->ds.n_media = s->n_media;
@@ -483,7 +490,8 @@ static int wf_run(rt_ctx* c, int w, int h, uint32_t s0, uint32_t s1, uint32_t k0
     if (rc) return rc;
     WfState& W = c->wf;
     W.n_slots = (uint32_t)n_slots; W.n_pixels = n_pixels; W.streams = streams;
-    const size_t lds = (size_t)c->stack_depth * RT_BLOCK * sizeof(int);
+    if (c->stack4 > WF_LDS_STACK + WF_OVF_STACK) { rt_set_error("wavefront integrator: BVH deeper than its traversal stack"); return RT_ERR_UNSUPPORTED; }
+    const size_t lds = (size_t)(c->stack4 < WF_LDS_STACK ? c->stack4 : WF_LDS_STACK) * RT_BLOCK * sizeof(int);
     HIPCHK(hipMemsetAsync(W.count, 0, 4 * sizeof(uint32_t), c->stream));
     const unsigned all_blocks = (unsigned)((n_slots + RT_BLOCK - 1) / RT_BLOCK);
     wf_init_kernel<V><<<dim3(all_blocks), RT_BLOCK, 0, c->stream>>>(c->ds, W, w, h, s0, s1, k0, k1, max_depth, c->d_counters);
@@ -539,7 +547,7 @@ extern "C" int rt_render_accumulate(rt_ctx* c, int w, int h, uint32_t s0, uint32
     HIPCHK(hipEventRecord(e0, c->stream));
     /* auto: the wavefront form pays off once traversal dominates (measured: 2.2x on the 1M-triangle scene,
      * 0.8x on the final scene with its 11k BVH items and media in the world list) */
-    const bool wavefront = c->integrator == RT_INTEGRATOR_WAVEFRONT || (c->integrator == RT_INTEGRATOR_AUTO && c->n_bvh_items >= RT_WF_AUTO_ITEMS);
+    const bool wavefront = c->integrator == RT_INTEGRATOR_WAVEFRONT || (c->integrator == RT_INTEGRATOR_AUTO && c->n_bvh_items >= RT_WF_AUTO_ITEMS && c->stack4 <= WF_LDS_STACK + WF_OVF_STACK);
     if (wavefront) {
         int wrc = (c->features & ~RT_V_BVH_TRI) == 0 ? wf_run<RT_V_BVH_TRI>(c, w, h, s0, s1, k0, k1, max_depth, background, accum)
                                                      : wf_run<RT_F_ALL>(c, w, h, s0, s1, k0, k1, max_depth, background, accum);

@@ -39,6 +39,8 @@ struct WfState {
 };
 
 enum { WF_NEED = 0, WF_SCAN = 1, WF_BVH = 2 };
+#define WF_LDS_STACK 20      /* traversal-stack entries per lane kept in LDS; deeper ones go to scratch */
+#define WF_OVF_STACK 44      /* entries of the scratch overflow: 3 per level of a 4-wide tree, rarely reached */
 #ifndef WF_PRIM_BATCH
 #define WF_CHUNK 256         /* queue entries a wave claims per atomic */
 #define WF_PRIM_BATCH 20     /* lanes at a leaf that make a primitive step worth running */
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_intersect_kernel(DScene S, WfStat
     const float tMin = .001f;
     const uint32_t whead = S.objs[S.world].head;
     const bool world_bvh = (obj_flags(whead) & RT_DOBJ_HAS_BVH) != 0;
-    const int world_root = S.objs[S.world].bvh_root;
+    const int world_root = S.objs[S.world].pad[0];       /* root of the 4-wide tree */
 
     int mode = WF_NEED;
     uint32_t slot = 0;
@@ -67,6 +69,9 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_intersect_kernel(DScene S, WfStat
     V3 id = mk(0.f, 0.f, 0.f);
     HitLite best = {FLT_MAX, -1, -1, 0};
     int pc = 0, gi = -1, ref = RT_REF_NONE, sp = 0, li = 0;
+    int ovf[WF_OVF_STACK];                      /* stack entries beyond WF_LDS_STACK (scratch) */
+#define WF_PUSH(v) { const int v_ = (v); if (sp < WF_LDS_STACK) stack[sp * RT_BLOCK] = v_; else ovf[sp - WF_LDS_STACK] = v_; ++sp; }
+#define WF_POP(dst) { dst = RT_REF_NONE; if (sp > 0) { --sp; dst = sp < WF_LDS_STACK ? stack[sp * RT_BLOCK] : ovf[sp - WF_LDS_STACK]; } }
     PathRng g;
     rng_start(g, k0, k1, 0u, 0u);
     uint32_t bounce = 0;
@@ -152,31 +157,34 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_intersect_kernel(DScene S, WfStat
         const int lfirst = (~ref) >> 4, lcount = ((~ref) & 15) + 1;
         const float4* src = reinterpret_cast<const float4*>(S.prog);
         if (in_scan) src = reinterpret_cast<const float4*>(S.prog + pc);
-        if (in_bvh) src = interior ? reinterpret_cast<const float4*>(S.nodes + ref)
+        if (in_bvh) src = interior ? reinterpret_cast<const float4*>(S.nodes4 + ref)
                                    : reinterpret_cast<const float4*>(S.leafs + (lfirst + li));
-        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0, q3 = q0;
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0, q3 = q0, q4 = q0, q5 = q0, q6 = q0;
         if (step) { q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3]; }
+        if (step && interior) { q4 = src[4]; q5 = src[5]; q6 = src[6]; }   /* a 4-wide node is 112 bytes of payload */
         if (!step) {
             /* this lane's kind of step was put off */
         } else if (in_bvh) {
             if (interior) {
-                const float lmin[3] = {q0.x, q0.y, q0.z}, lmax[3] = {q0.w, q1.x, q1.y};
-                const float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
-                const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
-                float tl, tr;
-                const bool hl = slab(lmin, lmax, rl.o, id, tMin, best.t, tl);
-                const bool hr = slab(rmin, rmax, rl.o, id, tMin, best.t, tr);
-                if (hl & hr) {
-                    const bool lnear = tl <= tr;
-                    stack[sp * RT_BLOCK] = lnear ? right : left;
-                    ++sp;
-                    ref = lnear ? left : right;
-                } else if (hl | hr) {
-                    ref = hl ? left : right;
-                } else {
-                    ref = RT_REF_NONE;
-                    if (sp > 0) { --sp; ref = stack[sp * RT_BLOCK]; }
-                }
+                const float b0[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y}, b1[6] = {q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+                const float b2[6] = {q3.x, q3.y, q3.z, q3.w, q4.x, q4.y}, b3[6] = {q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
+                int r0 = __float_as_int(q6.x), r1 = __float_as_int(q6.y), r2 = __float_as_int(q6.z), r3 = __float_as_int(q6.w);
+                float t0, t1, t2, t3;
+                /* a child that is missed (or an unused slot) sorts last with t = +inf */
+                if (!(slab(b0, b0 + 3, rl.o, id, tMin, best.t, t0) && r0 != RT_REF_NONE)) { t0 = FLT_MAX; r0 = RT_REF_NONE; }
+                if (!(slab(b1, b1 + 3, rl.o, id, tMin, best.t, t1) && r1 != RT_REF_NONE)) { t1 = FLT_MAX; r1 = RT_REF_NONE; }
+                if (!(slab(b2, b2 + 3, rl.o, id, tMin, best.t, t2) && r2 != RT_REF_NONE)) { t2 = FLT_MAX; r2 = RT_REF_NONE; }
+                if (!(slab(b3, b3 + 3, rl.o, id, tMin, best.t, t3) && r3 != RT_REF_NONE)) { t3 = FLT_MAX; r3 = RT_REF_NONE; }
+                /* 5-exchange sorting network on (t, ref), nearest first */
+#define WF_CSWAP(ta, ra, tb, rb) { const bool sw_ = tb < ta; const float tt_ = sw_ ? tb : ta; const int rr_ = sw_ ? rb : ra; tb = sw_ ? ta : tb; rb = sw_ ? ra : rb; ta = tt_; ra = rr_; }
+                WF_CSWAP(t0, r0, t1, r1) WF_CSWAP(t2, r2, t3, r3) WF_CSWAP(t0, r0, t2, r2) WF_CSWAP(t1, r1, t3, r3) WF_CSWAP(t1, r1, t2, r2)
+#undef WF_CSWAP
+                /* farthest first onto the stack, nearest entered next */
+                if (r3 != RT_REF_NONE) WF_PUSH(r3)
+                if (r2 != RT_REF_NONE) WF_PUSH(r2)
+                if (r1 != RT_REF_NONE) WF_PUSH(r1)
+                ref = r0;
+                if (ref == RT_REF_NONE) WF_POP(ref)
             } else {
                 const uint32_t head = __float_as_uint(q0.x);
                 const int oi = __float_as_int(q0.z);
@@ -188,8 +196,7 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_intersect_kernel(DScene S, WfStat
                 if (h) { best.t = t; best.obj = oi; best.grp = gi; best.aux = aux; }
                 if (++li == lcount) {
                     li = 0;
-                    ref = RT_REF_NONE;
-                    if (sp > 0) { --sp; ref = stack[sp * RT_BLOCK]; }
+                    WF_POP(ref)
                 }
             }
             if (ref == RT_REF_NONE) { mode = WF_SCAN; ++pc; }     /* the group is done: on with the world list */
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_intersect_kernel(DScene S, WfStat
                     rl = rw;
                     if (F & RT_F_XFORM) apply_chain(S, o, rl);
                     id = mk(1.f / rl.d.x, 1.f / rl.d.y, 1.f / rl.d.z);
-                    mode = WF_BVH; gi = obj; ref = o.bvh_root; sp = 0; li = 0;
+                    mode = WF_BVH; gi = obj; ref = o.pad[0]; sp = 0; li = 0;
                     /* pc stays on this record; it advances when the traversal ends */
                 } else {
                     generic_closest<F & ~RT_F_BVH>(S, obj, rw, tMin, best, &g, bounce, stack);
