@@ -8,6 +8,10 @@
 #include "../../include/rt_scene.h"
 #include "../api/rt_scene_api.h"
 
+#ifndef RT_DEFAULT_LEAF
+#define RT_DEFAULT_LEAF 2
+#endif
+
 namespace rt {
 
 /* Owns the storage behind an rt_flat_scene. */
@@ -25,7 +29,7 @@ struct FlatScene {
 
 struct LowerOptions {
     int bvh_min_children = 9;   /* groups with at least this many leaf children get a BVH */
-    int bvh_leaf_size    = 4;   /* max objects per BVH leaf */
+    int bvh_leaf_size    = RT_DEFAULT_LEAF;   /* max objects per BVH leaf */
 };
 
 /* Returns false and fills `err` when the graph uses nesting the tables cannot express. */

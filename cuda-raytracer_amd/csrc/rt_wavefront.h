@@ -39,6 +39,9 @@ struct WfState {
 };
 
 enum { WF_NEED = 0, WF_SCAN = 1, WF_BVH = 2 };
+#ifndef WF_INTERSECT_WAVES
+#define WF_INTERSECT_WAVES 4   /* waves per SIMD the intersect kernel is compiled for */
+#endif
 #define WF_LDS_STACK 20      /* traversal-stack entries per lane kept in LDS; deeper ones go to scratch */
 #define WF_OVF_STACK 44      /* entries of the scratch overflow: 3 per level of a 4-wide tree, rarely reached */
 #ifndef WF_PRIM_BATCH
@@ -50,7 +53,7 @@ enum { WF_NEED = 0, WF_SCAN = 1, WF_BVH = 2 };
 
 /* ------------------------------------------------------------------ intersect -- */
 template <uint32_t F>
-__global__ __launch_bounds__(RT_BLOCK) void wf_intersect_kernel(DScene S, WfState W, int qi, uint32_t k0, uint32_t k1,
+__global__ __launch_bounds__(RT_BLOCK, WF_INTERSECT_WAVES) void wf_intersect_kernel(DScene S, WfState W, int qi, uint32_t k0, uint32_t k1,
                                                                 unsigned long long* __restrict__ counters)
 {
     extern __shared__ int stack_mem[];
