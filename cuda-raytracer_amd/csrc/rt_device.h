@@ -451,19 +451,31 @@ __device__ __forceinline__ HitLite closest_hit(const DScene& S, const DRay& r, f
         const ProgRec nxt = prog_load(pc);
         if (kind == RT_P_RECT) {
             if (F & RT_F_PLANAR) {
+                /* The record's axis is wave-uniform: the ray components are picked with selects on a scalar
+                 * condition and ONE body (Rectangle.cuh:24-38 with a = x, b = y, k = z) serves the three
+                 * kinds; three bodies behind a scalar branch were merged by the compiler into one behind
+                 * ~15 register moves.  The winner is kept with selects as well. */
                 const int ka = (int)((cur.head >> 8) & 0xffu);
+                DRay ra;
+                ra.o = mk(ka == 0 ? rl.o.y : rl.o.x, ka == 2 ? rl.o.y : rl.o.z, ka == 2 ? rl.o.z : (ka == 1 ? rl.o.y : rl.o.x));
+                ra.d = mk(ka == 0 ? rl.d.y : rl.d.x, ka == 2 ? rl.d.y : rl.d.z, ka == 2 ? rl.d.z : (ka == 1 ? rl.d.y : rl.d.x));
+                ra.time = rl.time;
                 float t;
-                bool h;
-                if (ka == 2) h = rect_t<2>(cur.v1, cur.v2, cur.v3, cur.v4, cur.v0, rl, tMin, best.t, t);
-                else if (ka == 1) h = rect_t<1>(cur.v1, cur.v2, cur.v3, cur.v4, cur.v0, rl, tMin, best.t, t);
-                else h = rect_t<0>(cur.v1, cur.v2, cur.v3, cur.v4, cur.v0, rl, tMin, best.t, t);
-                if (h) { best.t = t; best.obj = cur.obj; best.grp = -1; best.aux = (int)((cur.head >> 16) & 0xffu); }
+                const bool h = rect_t<2>(cur.v1, cur.v2, cur.v3, cur.v4, cur.v0, ra, tMin, best.t, t);
+                best.t = h ? t : best.t;
+                best.obj = h ? cur.obj : best.obj;
+                best.grp = h ? -1 : best.grp;
+                best.aux = h ? (int)((cur.head >> 16) & 0xffu) : best.aux;
             }
         } else if (kind == RT_P_BOX) {
             if (F & RT_F_PLANAR) {
                 const float f[6] = {cur.v0, cur.v1, cur.v2, cur.v3, cur.v4, cur.v5};
                 float t; int face;
-                if (box_t(f, rl, tMin, best.t, t, face)) { best.t = t; best.obj = cur.obj; best.grp = -1; best.aux = face; }
+                const bool h = box_t(f, rl, tMin, best.t, t, face);
+                best.t = h ? t : best.t;
+                best.obj = h ? cur.obj : best.obj;
+                best.grp = h ? -1 : best.grp;
+                best.aux = h ? face : best.aux;
             }
         } else if (kind == RT_P_XFORM) {
             if (F & RT_F_XFORM) {
