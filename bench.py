@@ -234,10 +234,15 @@ def main():
             roof.update({"flops_per_ray": fpr, "bytes_per_ray": bpr,
                          "valu_peak_TFLOPs": PEAK_VALU_TFLOPS, "valu_achieved_TFLOPs": ach_f, "valu_frac": ach_f / PEAK_VALU_TFLOPS,
                          "hbm_peak_GBs": PEAK_HBM_GBS, "hbm_achieved_GBs": ach_b, "hbm_frac": ach_b / PEAK_HBM_GBS})
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        # counters cannot be read in-process: the per-call HBM bytes and the PMC-derived shares come from the
+        # committed rocprofv3 passes of this same command (tools/prof_round.sh -> profiles/pmc_summary.json)
+        tpath = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(tpath):
             try:
-                roof["traffic"] = json.load(open(tpath)).get(out["config"]["workload"])
+                pm = json.load(open(tpath)).get(out["config"]["workload"])
+                if pm:
+                    roof["traffic"] = pm.get("traffic_bytes")
+                    roof["pmc"] = {k: v for k, v in pm.items() if k != "traffic_bytes"}
             except Exception:
                 pass
         out["roofline"] = roof

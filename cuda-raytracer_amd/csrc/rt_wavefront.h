@@ -71,7 +71,7 @@ __global__ __launch_bounds__(RT_BLOCK, WF_INTERSECT_WAVES) void wf_intersect_ker
     DRay rw = {mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f), 0.f}, rl = rw;
     V3 id = mk(0.f, 0.f, 0.f);
     HitLite best = {FLT_MAX, -1, -1, 0};
-    int pc = 0, gi = -1, ref = RT_REF_NONE, sp = 0, li = 0;
+    int pc = 0, gi = -1, ref = RT_REF_NONE, pleaf = RT_REF_NONE, sp = 0, li = 0;
     int ovf[WF_OVF_STACK];                      /* stack entries beyond WF_LDS_STACK (scratch) */
 #define WF_PUSH(v) { const int v_ = (v); if (sp < WF_LDS_STACK) stack[sp * RT_BLOCK] = v_; else ovf[sp - WF_LDS_STACK] = v_; ++sp; }
 #define WF_POP(dst) { dst = RT_REF_NONE; if (sp > 0) { --sp; dst = sp < WF_LDS_STACK ? stack[sp * RT_BLOCK] : ovf[sp - WF_LDS_STACK]; } }
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(RT_BLOCK, WF_INTERSECT_WAVES) void wf_intersect_ker
                     g.sample = __float_as_uint(W.att[slot].w);
                     best.t = FLT_MAX; best.obj = -1; best.grp = -1; best.aux = 0;
                     rl = rw;
-                    sp = 0; li = 0;
+                    sp = 0; li = 0; pleaf = RT_REF_NONE;
                     ++n_rays;
                     if ((F & RT_F_BVH) && world_bvh) {
                         mode = WF_BVH; gi = -1; ref = world_root; pc = -1;
@@ -138,72 +138,79 @@ __global__ __launch_bounds__(RT_BLOCK, WF_INTERSECT_WAVES) void wf_intersect_ker
             continue;                            /* fewer than 16 idle lanes cannot happen here: all 64 are idle */
         }
 
-        /* ---- one step ----
-         * The three kinds of step cost very differently (a node ~60 VALU instructions, a triangle ~130, a
-         * scan record ~50-100) and a trip pays for every kind any lane runs.  A kind with few takers is
-         * therefore put off until enough lanes want it, or until the cheaper kinds have run dry: its lanes
-         * sit out a trip or two, and the wave stops paying a triangle test for two or three lanes. */
+        /* ---- one trip ----
+         * The kinds of step cost very differently (a 4-wide node ~130 VALU instructions, a triangle ~130, a
+         * scan record 50-100) and a trip pays for every kind any lane runs, so each kind should run with as
+         * many lanes as possible:
+         *  - a lane that reaches a leaf does not stop to test it: the leaf is POSTPONED (`pleaf`) and the
+         *    lane goes on with the next node from its stack; it can take a node step and a primitive step in
+         *    the same trip, and only stalls when a second leaf turns up before the first is finished;
+         *  - primitive steps run once WF_PRIM_BATCH lanes hold a postponed leaf, or the node steps run low;
+         *    scan records likewise.
+         * The closest hit does not depend on the order in which a ray's leaves are tested (exact ties aside). */
         const bool in_bvh = mode == WF_BVH;
         const bool interior = in_bvh && ref >= 0;
-        const bool at_leaf = in_bvh && ref < 0;
+        const bool has_leaf = in_bvh && pleaf != RT_REF_NONE;
         const bool in_scan = mode == WF_SCAN;
-        const int n_node = __popcll(__ballot(interior)), n_prim = __popcll(__ballot(at_leaf)), n_scan = __popcll(__ballot(in_scan));
+        const int n_node = __popcll(__ballot(interior)), n_prim = __popcll(__ballot(has_leaf)), n_scan = __popcll(__ballot(in_scan));
         const bool do_prim = n_prim >= WF_PRIM_BATCH || (n_prim > 0 && n_node < WF_NODE_LOW);
         const bool do_scan = n_scan >= WF_SCAN_BATCH || (n_scan > 0 && n_node < WF_NODE_LOW && !do_prim) || (n_scan > 0 && n_node + n_prim == 0);
-        const bool step = interior || (at_leaf && do_prim) || (in_scan && do_scan);
+        const bool prim_step = has_leaf && do_prim;
+        const bool scan_step = in_scan && do_scan;
 #ifdef RT_STAMPS
         {
             const int nb = __popcll(__ballot(mode != WF_NEED));
             dg[0] += 1; dg[1] += nb; dg[2] += n_node; dg[3] += do_prim ? n_prim : 0; dg[4] += do_scan ? n_scan : 0; dg[5] += do_scan ? 1 : 0; dg[6] += do_prim ? 1 : 0;
         }
 #endif
-        const int lfirst = (~ref) >> 4, lcount = ((~ref) & 15) + 1;
-        const float4* src = reinterpret_cast<const float4*>(S.prog);
-        if (in_scan) src = reinterpret_cast<const float4*>(S.prog + pc);
-        if (in_bvh) src = interior ? reinterpret_cast<const float4*>(S.nodes4 + ref)
-                                   : reinterpret_cast<const float4*>(S.leafs + (lfirst + li));
-        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0, q3 = q0, q4 = q0, q5 = q0, q6 = q0;
-        if (step) { q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3]; }
-        if (step && interior) { q4 = src[4]; q5 = src[5]; q6 = src[6]; }   /* a 4-wide node is 112 bytes of payload */
-        if (!step) {
-            /* this lane's kind of step was put off */
-        } else if (in_bvh) {
-            if (interior) {
-                const float b0[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y}, b1[6] = {q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
-                const float b2[6] = {q3.x, q3.y, q3.z, q3.w, q4.x, q4.y}, b3[6] = {q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
-                int r0 = __float_as_int(q6.x), r1 = __float_as_int(q6.y), r2 = __float_as_int(q6.z), r3 = __float_as_int(q6.w);
-                float t0, t1, t2, t3;
-                /* a child that is missed (or an unused slot) sorts last with t = +inf */
-                if (!(slab(b0, b0 + 3, rl.o, id, tMin, best.t, t0) && r0 != RT_REF_NONE)) { t0 = FLT_MAX; r0 = RT_REF_NONE; }
-                if (!(slab(b1, b1 + 3, rl.o, id, tMin, best.t, t1) && r1 != RT_REF_NONE)) { t1 = FLT_MAX; r1 = RT_REF_NONE; }
-                if (!(slab(b2, b2 + 3, rl.o, id, tMin, best.t, t2) && r2 != RT_REF_NONE)) { t2 = FLT_MAX; r2 = RT_REF_NONE; }
-                if (!(slab(b3, b3 + 3, rl.o, id, tMin, best.t, t3) && r3 != RT_REF_NONE)) { t3 = FLT_MAX; r3 = RT_REF_NONE; }
-                /* 5-exchange sorting network on (t, ref), nearest first */
+        /* the loads of both steps of the trip go out together */
+        const int lfirst = (~pleaf) >> 4, lcount = ((~pleaf) & 15) + 1;
+        const float4* nsrc = reinterpret_cast<const float4*>(S.nodes4 + (interior ? ref : 0));
+        const float4* src = prim_step ? reinterpret_cast<const float4*>(S.leafs + (lfirst + li))
+                                      : reinterpret_cast<const float4*>(S.prog + (scan_step ? pc : 0));
+        float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0, n3 = n0, n4 = n0, n5 = n0, n6 = n0;
+        float4 q0 = n0, q1 = n0, q2 = n0, q3 = n0;
+        if (interior) { n0 = nsrc[0]; n1 = nsrc[1]; n2 = nsrc[2]; n3 = nsrc[3]; n4 = nsrc[4]; n5 = nsrc[5]; n6 = nsrc[6]; }
+        if (prim_step || scan_step) { q0 = src[0]; q1 = src[1]; }
+        if (prim_step) { q2 = src[2]; q3 = src[3]; }
+
+        if (interior) {
+            const float b0[6] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y}, b1[6] = {n1.z, n1.w, n2.x, n2.y, n2.z, n2.w};
+            const float b2[6] = {n3.x, n3.y, n3.z, n3.w, n4.x, n4.y}, b3[6] = {n4.z, n4.w, n5.x, n5.y, n5.z, n5.w};
+            int r0 = __float_as_int(n6.x), r1 = __float_as_int(n6.y), r2 = __float_as_int(n6.z), r3 = __float_as_int(n6.w);
+            float t0, t1, t2, t3;
+            /* a child that is missed (or an unused slot) sorts last with t = +inf */
+            if (!(slab(b0, b0 + 3, rl.o, id, tMin, best.t, t0) && r0 != RT_REF_NONE)) { t0 = FLT_MAX; r0 = RT_REF_NONE; }
+            if (!(slab(b1, b1 + 3, rl.o, id, tMin, best.t, t1) && r1 != RT_REF_NONE)) { t1 = FLT_MAX; r1 = RT_REF_NONE; }
+            if (!(slab(b2, b2 + 3, rl.o, id, tMin, best.t, t2) && r2 != RT_REF_NONE)) { t2 = FLT_MAX; r2 = RT_REF_NONE; }
+            if (!(slab(b3, b3 + 3, rl.o, id, tMin, best.t, t3) && r3 != RT_REF_NONE)) { t3 = FLT_MAX; r3 = RT_REF_NONE; }
+            /* 5-exchange sorting network on (t, ref), nearest first */
 #define WF_CSWAP(ta, ra, tb, rb) { const bool sw_ = tb < ta; const float tt_ = sw_ ? tb : ta; const int rr_ = sw_ ? rb : ra; tb = sw_ ? ta : tb; rb = sw_ ? ra : rb; ta = tt_; ra = rr_; }
-                WF_CSWAP(t0, r0, t1, r1) WF_CSWAP(t2, r2, t3, r3) WF_CSWAP(t0, r0, t2, r2) WF_CSWAP(t1, r1, t3, r3) WF_CSWAP(t1, r1, t2, r2)
+            WF_CSWAP(t0, r0, t1, r1) WF_CSWAP(t2, r2, t3, r3) WF_CSWAP(t0, r0, t2, r2) WF_CSWAP(t1, r1, t3, r3) WF_CSWAP(t1, r1, t2, r2)
 #undef WF_CSWAP
-                /* farthest first onto the stack, nearest entered next */
-                if (r3 != RT_REF_NONE) WF_PUSH(r3)
-                if (r2 != RT_REF_NONE) WF_PUSH(r2)
-                if (r1 != RT_REF_NONE) WF_PUSH(r1)
-                ref = r0;
-                if (ref == RT_REF_NONE) WF_POP(ref)
-            } else {
-                const uint32_t head = __float_as_uint(q0.x);
-                const int oi = __float_as_int(q0.z);
-                const float f[13] = {q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-                float t; int aux;
-                bool h;
-                if (!(F & RT_F_XFORM) || obj_op_count(head) == 0) h = prim_t<F>(obj_type(head), f, rl, tMin, best.t, t, aux);
-                else h = leaf_t<F>(S, S.objs[oi], rl, tMin, best.t, t, aux);
-                if (h) { best.t = t; best.obj = oi; best.grp = gi; best.aux = aux; }
-                if (++li == lcount) {
-                    li = 0;
-                    WF_POP(ref)
-                }
-            }
-            if (ref == RT_REF_NONE) { mode = WF_SCAN; ++pc; }     /* the group is done: on with the world list */
-        } else {
+            /* farthest first onto the stack, nearest entered next */
+            if (r3 != RT_REF_NONE) WF_PUSH(r3)
+            if (r2 != RT_REF_NONE) WF_PUSH(r2)
+            if (r1 != RT_REF_NONE) WF_PUSH(r1)
+            ref = r0;
+            if (ref == RT_REF_NONE) WF_POP(ref)
+        }
+        if (prim_step) {
+            const uint32_t head = __float_as_uint(q0.x);
+            const int oi = __float_as_int(q0.z);
+            const float f[13] = {q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+            float t; int aux;
+            bool h;
+            if (!(F & RT_F_XFORM) || obj_op_count(head) == 0) h = prim_t<F>(obj_type(head), f, rl, tMin, best.t, t, aux);
+            else h = leaf_t<F>(S, S.objs[oi], rl, tMin, best.t, t, aux);
+            if (h) { best.t = t; best.obj = oi; best.grp = gi; best.aux = aux; }
+            if (++li == lcount) { li = 0; pleaf = RT_REF_NONE; }
+        }
+        if (in_bvh) {
+            /* a leaf reference in `ref` moves to the postponed slot as soon as that is free */
+            if (pleaf == RT_REF_NONE && ref < 0 && ref != RT_REF_NONE) { pleaf = ref; li = 0; WF_POP(ref) }
+            if (ref == RT_REF_NONE && pleaf == RT_REF_NONE) { mode = WF_SCAN; ++pc; }   /* the group is done: on with the world list */
+        } else if (scan_step) {
             const uint32_t head = __float_as_uint(q0.x);
             const int kind = (int)(head & 0xffu);
             const int obj = __float_as_int(q0.y);
@@ -253,7 +260,7 @@ __global__ __launch_bounds__(RT_BLOCK, WF_INTERSECT_WAVES) void wf_intersect_ker
                     rl = rw;
                     if (F & RT_F_XFORM) apply_chain(S, o, rl);
                     id = mk(1.f / rl.d.x, 1.f / rl.d.y, 1.f / rl.d.z);
-                    mode = WF_BVH; gi = obj; ref = o.pad[0]; sp = 0; li = 0;
+                    mode = WF_BVH; gi = obj; ref = o.pad[0]; pleaf = RT_REF_NONE; sp = 0; li = 0;
                     /* pc stays on this record; it advances when the traversal ends */
                 } else {
                     generic_closest<F & ~RT_F_BVH>(S, obj, rw, tMin, best, &g, bounce, stack);

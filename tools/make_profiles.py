@@ -39,9 +39,25 @@ for wl, dirs in (("cornell", ["cornell_fetch", "cornell_write", "cornell_sq", "c
             for (k, c), (v, n) in sorted(a.items()):
                 o.write("%-34s %-24s sum=%.6g launches=%d\n" % (k[:34], c, v, n))
                 allsum[(wl, k.split("<")[0].replace("void ", ""), c)] = v
-traffic = {
-    "cornell_1024x1024_1024spp": (2.0 * allsum[("cornell", "render_kernel", "FETCH_SIZE")] + allsum[("cornell", "render_kernel", "WRITE_SIZE")]) * 1024.0,
-    "tri_mesh_1920x1080_32spp": sum(v for (wl, k, c), v in allsum.items() if wl == "tri" and c in ("FETCH_SIZE", "WRITE_SIZE")) * 1024.0,
+def g(wl, k, c):
+    return allsum.get((wl, k, c), 0.0)
+
+def derived(wl, k):
+    """VALU busy share of the SIMDs (SQ_ACTIVE_INST_VALU counts quad-cycles; GRBM_GUI_ACTIVE is summed over the
+    8 XCDs), lane efficiency (active lanes per VALU instruction / 64) and, where counted, the L2 hit rate"""
+    simd_cycles = g(wl, k, "GRBM_GUI_ACTIVE") / 8.0 * 1024.0
+    out = {"valu_busy": 4.0 * g(wl, k, "SQ_ACTIVE_INST_VALU") / simd_cycles if simd_cycles else None,
+           "lane_efficiency": g(wl, k, "SQ_THREAD_CYCLES_VALU") / (64.0 * g(wl, k, "SQ_ACTIVE_INST_VALU")) if g(wl, k, "SQ_ACTIVE_INST_VALU") else None,
+           "wait_share_of_wave_cycles": g(wl, k, "SQ_WAIT_ANY") / g(wl, k, "SQ_WAVE_CYCLES") if g(wl, k, "SQ_WAVE_CYCLES") else None}
+    if g(wl, k, "TCC_REQ_sum"):
+        out["l2_hit_rate"] = g(wl, k, "TCC_HIT_sum") / g(wl, k, "TCC_REQ_sum")
+    return out
+
+summary = {
+    "cornell_1024x1024_1024spp": dict(derived("cornell", "render_kernel"), kernel="render_kernel", source=tag,
+        traffic_bytes=(2.0 * g("cornell", "render_kernel", "FETCH_SIZE") + g("cornell", "render_kernel", "WRITE_SIZE")) * 1024.0),
+    "tri_mesh_1920x1080_32spp": dict(derived("tri", "wf_intersect_kernel"), kernel="wf_intersect_kernel", source=tag,
+        traffic_bytes=sum(v for (wl, k, c), v in allsum.items() if wl == "tri" and c in ("FETCH_SIZE", "WRITE_SIZE")) * 1024.0),
 }
-json.dump(traffic, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
-print(traffic)
+json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1))
