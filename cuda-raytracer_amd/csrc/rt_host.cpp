@@ -186,6 +186,8 @@ bool rt_pack_bvh(const rt_flat_scene* s, std::vector<DObj>& objs, std::vector<DN
     return true;
 }
 
+static bool obj_is_bvh_group(const DObj& o) { return (o.head & 0xffu) == RT_OBJ_GROUP && ((o.head >> 8) & RT_DOBJ_HAS_BVH); }
+
 void rt_pack_bvh4(const rt_flat_scene* s, std::vector<DObj>& objs, std::vector<DNode4>& nodes4, int* depth)
 {
     nodes4.clear();
@@ -342,6 +344,57 @@ uint32_t rt_scene_features(const rt_flat_scene* s)
     }
     if (s->camera.lens_radius != 0.f) f |= RT_F_LENS;
     return f;
+}
+
+extern "C" uint32_t rt_flat_features(const rt_flat_scene* flat)
+{
+    std::string why;
+    if (!flat || !rt_validate_scene(flat, why, nullptr)) return 0u;
+    return rt_scene_features(flat);
+}
+
+extern "C" int rt_flat_program(const rt_flat_scene* flat, uint32_t* out_words, int cap_records)
+{
+    std::string why;
+    if (!flat || cap_records < 0 || (cap_records && !out_words)) { rt_set_error("rt_flat_program: bad arguments"); return RT_ERR_ARG; }
+    if (!rt_validate_scene(flat, why, nullptr)) { rt_set_error("rt_flat_program: invalid scene: " + why); return RT_ERR_ARG; }
+    std::vector<DProg> prog;
+    rt_pack_program(flat, prog);
+    const size_t n = prog.size() < (size_t)cap_records ? prog.size() : (size_t)cap_records;
+    if (n) std::memcpy(out_words, prog.data(), n * sizeof(DProg));
+    return (int)prog.size();
+}
+
+extern "C" int rt_flat_bvh_stats(const rt_flat_scene* flat, int* nodes2, int* depth2, int* nodes4, int* depth4)
+{
+    std::string why;
+    if (!flat || !rt_validate_scene(flat, why, nullptr)) { rt_set_error("rt_flat_bvh_stats: invalid scene: " + why); return RT_ERR_ARG; }
+    std::vector<DObj> objs((size_t)flat->n_objects);
+    rt_pack_objects(flat, objs.data());
+    std::vector<DNode> n2;
+    std::vector<DObj> leafs;
+    std::vector<DNode4> n4;
+    int d2 = 0, d4 = 0;
+    if (!rt_pack_bvh(flat, objs, n2, leafs, &d2, why)) { rt_set_error("rt_flat_bvh_stats: " + why); return RT_ERR_UNSUPPORTED; }
+    rt_pack_bvh4(flat, objs, n4, &d4);
+    /* every leaf reference of both trees must land inside the leaf table, and together cover it once */
+    std::vector<uint8_t> seen(leafs.size(), 0);
+    size_t covered = 0;
+    auto leaf = [&](int32_t ref) {
+        if (ref >= 0 || ref == RT_REF_NONE) return true;
+        const uint32_t first = (uint32_t)(~ref) >> 4, count = ((uint32_t)(~ref) & 15u) + 1u;
+        if ((size_t)first + count > leafs.size()) return false;
+        for (uint32_t i = 0; i < count; ++i) { if (seen[first + i]) return false; seen[first + i] = 1; ++covered; }
+        return true;
+    };
+    for (const DNode4& n : n4) for (int k = 0; k < 4; ++k) if (!leaf(n.ref[k])) { rt_set_error("rt_flat_bvh_stats: bad leaf reference in a 4-wide node"); return RT_ERR_UNSUPPORTED; }
+    for (const DObj& o : objs) if ((obj_is_bvh_group(o)) && !leaf(o.pad[0])) { rt_set_error("rt_flat_bvh_stats: bad root reference"); return RT_ERR_UNSUPPORTED; }
+    if (covered != leafs.size()) { rt_set_error("rt_flat_bvh_stats: the 4-wide trees do not cover the leaf table exactly once"); return RT_ERR_UNSUPPORTED; }
+    if (nodes2) *nodes2 = (int)n2.size();
+    if (depth2) *depth2 = d2;
+    if (nodes4) *nodes4 = (int)n4.size();
+    if (depth4) *depth4 = d4;
+    return RT_OK;
 }
 
 extern "C" int rt_quantise_rgb8(const float* rgb, int width, int height, uint8_t* out)

@@ -118,6 +118,16 @@ int  rt_synchronize(rt_ctx* c);
 int  rt_get_counters(rt_ctx* c, rt_counters* out);   /* synchronizes first */
 int  rt_reset_counters(rt_ctx* c);
 
+/* ---- introspection (host only, no GPU): what rt_scene_upload derives from the tables ---- */
+/* RT_F_* feature bits of the scene (cuda-raytracer_amd/csrc/rt_host.h): they select the kernel variant */
+uint32_t rt_flat_features(const rt_flat_scene* flat);
+/* the world list as the 32-byte scan records the closest-hit scan executes (replaces walking
+ * HitableList::list, HitableList.cuh:17-32): writes up to cap records of 8 words and returns how many the
+ * scene has (terminators included), or a negative rt_status */
+int  rt_flat_program(const rt_flat_scene* flat, uint32_t* out_words, int cap_records);
+/* sizes of the device BVHs: two-box nodes, four-box nodes, traversal stack entries each needs */
+int  rt_flat_bvh_stats(const rt_flat_scene* flat, int* nodes2, int* depth2, int* nodes4, int* depth4);
+
 /* ---- image output (replaces the quantise loop of main(), main.cu:668-697) ---- */
 /* rgb (host, W*H*3, row 0 = bottom) -> 8-bit, rows flipped to top-down, int(255.99*c) clamped to
  * 0..255 (the reference does not clamp and wraps above 1).  out is W*H*3 bytes. */
