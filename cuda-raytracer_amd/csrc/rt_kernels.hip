@@ -35,12 +35,13 @@
 #define RT_WF_SLOTS (1u << 23)
 #endif
 #define RT_N_COUNTERS 16        /* rays, samples, then diagnostic slots */
-#ifndef RT_RENDER_WAVES_BVH
-#define RT_RENDER_WAVES_BVH 3  /* BVH variants: <=168 VGPRs, no spills */
-#endif
-#ifndef RT_RENDER_WAVES
-#define RT_RENDER_WAVES 4      /* waves per SIMD the render kernel is compiled for (<=128 VGPRs) */
-#endif
+/* waves per SIMD each render-kernel variant is compiled for (its VGPR budget).  Measured on the Cornell
+ * variant: 4 -> 19.7, 5 -> 20.6, 6 -> 21.1 (80 VGPRs, 64 B/lane of spill), 8 -> 18.1 Grays/s: the kernel is
+ * VALU-issue bound and a sixth wave fills issue slots the others leave; the larger variants spill too much. */
+constexpr int rt_render_waves(uint32_t F)
+{
+    return (F & RT_F_BVH) ? 3 : ((F & ~(RT_F_PLANAR | RT_F_XFORM | RT_F_MEDIA | RT_F_ISO)) == 0 ? 6 : 4);
+}
 
 /* Diagnostic build only (-DRT_STAMPS, tools/diag): shader-clock time of each section of the render
  * loop, summed per wave into counters[4 + section].  No stamp executes in the shipped library. */
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(RT_BLOCK) void trace_primary_kernel(DScene S, int W
 }
 
 template <uint32_t F, int BG>
-__global__ __launch_bounds__(RT_BLOCK, (F & RT_F_BVH) ? RT_RENDER_WAVES_BVH : RT_RENDER_WAVES) void render_kernel(DScene S, int W, int H, uint32_t s_begin, uint32_t s_end,
+__global__ __launch_bounds__(RT_BLOCK, rt_render_waves(F)) void render_kernel(DScene S, int W, int H, uint32_t s_begin, uint32_t s_end,
                                                            uint32_t k0, uint32_t k1, int max_depth,
                                                            float* __restrict__ accum,
                                                            unsigned long long* __restrict__ counters)
