@@ -36,11 +36,12 @@
 #endif
 #define RT_N_COUNTERS 16        /* rays, samples, then diagnostic slots */
 /* waves per SIMD each render-kernel variant is compiled for (its VGPR budget).  Measured on the Cornell
- * variant: 4 -> 19.7, 5 -> 20.6, 6 -> 21.1 (80 VGPRs, 64 B/lane of spill), 8 -> 18.1 Grays/s: the kernel is
- * VALU-issue bound and a sixth wave fills issue slots the others leave; the larger variants spill too much. */
+ * variant: 4 -> 19.7, 5 -> 20.6, 6 -> 21.1, 8 -> 18.1 Grays/s.  The kernel is VALU-issue bound and more waves
+ * fill issue slots; 6 needs 80 VGPRs and spills 64 B/lane, which showed as 7.6 GB of scratch traffic per
+ * launch against 26 MB of algorithmic bytes, so the spill-free 5 is used.  The larger variants spill earlier. */
 constexpr int rt_render_waves(uint32_t F)
 {
-    return (F & RT_F_BVH) ? 3 : ((F & ~(RT_F_PLANAR | RT_F_XFORM | RT_F_MEDIA | RT_F_ISO)) == 0 ? 6 : 4);
+    return (F & RT_F_BVH) ? 3 : ((F & ~(RT_F_PLANAR | RT_F_XFORM)) == 0 ? 5 : 4);
 }
 
 /* Diagnostic build only (-DRT_STAMPS, tools/diag): shader-clock time of each section of the render
