@@ -91,3 +91,20 @@ def test_from_flat_round_trip_and_validation(binding, oracle_mod):
     h3 = C.c_void_p()
     assert binding.lib().rt_scene_from_flat(sc.flat, C.byref(h3)) < 0
     f.bvh_items[0] = keep
+
+
+def test_headers_are_plain_c(tmp_path):
+    """the boundary is a C ABI: include/rt_api.h and rt_scene.h compile as C99 and as C++ with nothing else on
+    the include path, and the structs have the sizes the bindings assume"""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "rt_api.h"\n'
+                   'typedef char a1[sizeof(rt_object) == 104 ? 1 : -1];\n'
+                   'typedef char a2[sizeof(rt_bvh_node) == 32 ? 1 : -1];\n'
+                   'typedef char a3[sizeof(rt_hit_record) == 52 ? 1 : -1];\n'
+                   'typedef char a4[sizeof(rt_camera) == 96 ? 1 : -1];\n'
+                   'typedef char a5[sizeof(rt_xform_op) == 16 && sizeof(rt_material) == 16 && sizeof(rt_texture) == 40 ? 1 : -1];\n'
+                   'int main(void) { const char* (*f)(void) = rt_last_error; return f != rt_last_error; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)])
