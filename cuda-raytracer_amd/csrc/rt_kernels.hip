@@ -280,7 +280,6 @@ struct rt_ctx {
     void* d_objs = nullptr;  void* d_ops = nullptr;   void* d_mats = nullptr; void* d_texs = nullptr;
     void* d_image = nullptr; void* d_nodes = nullptr; void* d_leafs = nullptr; void* d_prog = nullptr; void* d_nodes4 = nullptr;
     unsigned long long* d_counters = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     /* render launches whose event pair has not been read back yet are timed lazily */
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double render_ms = 0.0, last_ms = 0.0;
@@ -501,7 +500,13 @@ static int wf_run(rt_ctx* c, int w, int h, uint32_t s0, uint32_t s1, uint32_t k0
     uint32_t known = (uint32_t)n_slots;      /* upper bound of the current queue's length (it never grows) */
     int cur = 0;
     const int batch = 4;
+    /* every iteration advances every live path by one bounce, and a slot runs at most ceil(samples / streams)
+     * paths of at most max_depth bounces: the loop cannot legitimately run longer than this */
+    const unsigned long long max_iters = ((unsigned long long)(s1 - s0 + streams - 1) / streams) * (unsigned long long)(max_depth > 0 ? max_depth : 1) + (unsigned)batch;
+    unsigned long long iters = 0;
     while (known > 0) {
+        if (iters > max_iters) { rt_set_error("wavefront integrator: the path queue did not drain"); return RT_ERR_HIP; }
+        iters += (unsigned)batch;
         for (int b = 0; b < batch; ++b) {
             wf_reset_kernel<<<1, 1, 0, c->stream>>>(W.count, cur ^ 1);
             unsigned blocks = (known + RT_BLOCK - 1) / RT_BLOCK;
