@@ -124,7 +124,7 @@ float curand_uniform(curandState* state);
 /* ---------------------------------------------------------------- textures -- */
 class Texture : public rt::Node {
 public:
-    enum Kind { CONSTANT, CHECKER, IMAGE };
+    enum Kind { CONSTANT, CHECKER, IMAGE, NOISE };
     virtual Kind kind() const = 0;
 };
 class ConstantTexture : public Texture {
@@ -148,6 +148,19 @@ public:
     ImageTexture() : data(nullptr), width(0), height(0) {}
     ImageTexture(unsigned char* pixels, int A, int B) : data(pixels), width(A), height(B) {}
     Kind kind() const override { return IMAGE; }
+};
+/* Perlin "marble".  The reference's Texture.cuh has no noise class (it stops at ImageTexture); this is
+ * the noise_texture of "Ray Tracing: The Next Week" ch. 5 in the reference's style: a Texture that owns its
+ * gradient and permutation tables and, like ConstantMedium and BvhNode, takes the scene's curandState to
+ * fill them (a null state = a private stream seeded 419).
+ *   value(u,v,p) = (1,1,1) * 0.5 * (1 + sin(scale * p.z + 10 * turb(p, 7))) */
+class NoiseTexture : public Texture {
+public:
+    float scale;
+    float ranvec[256][3];                 /* unit gradient vectors */
+    unsigned char permX[256], permY[256], permZ[256];
+    NoiseTexture(float sc = 1.f, curandState* randState = nullptr);
+    Kind kind() const override { return NOISE; }
 };
 
 /* --------------------------------------------------------------- materials -- */

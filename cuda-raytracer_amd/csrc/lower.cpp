@@ -15,6 +15,32 @@
 #include <map>
 
 /* ------------------------------------------------------------------ arena -- */
+/* perlin_generate / perlin_generate_perm of "The Next Week" ch. 5, drawing from the scene's stream.
+ * curand_uniform is (0,1], the book's drand48 [0,1): the shuffle target is clamped to i. */
+NoiseTexture::NoiseTexture(float sc, curandState* randState) : scale(sc)
+{
+    curandState own;
+    if (!randState) { curand_init(419, 0, 0, &own); randState = &own; }
+    for (int i = 0; i < 256; ++i) {
+        float x = -1.f + 2.f * curand_uniform(randState);
+        float y = -1.f + 2.f * curand_uniform(randState);
+        float z = -1.f + 2.f * curand_uniform(randState);
+        Vector3 g = unitVector(Vector3(x, y, z));
+        for (int a = 0; a < 3; ++a) ranvec[i][a] = g.e[a];
+    }
+    unsigned char* perms[3] = {permX, permY, permZ};
+    for (unsigned char* p : perms) {
+        for (int i = 0; i < 256; ++i) p[i] = (unsigned char)i;
+        for (int i = 255; i > 0; --i) {
+            int target = int(curand_uniform(randState) * (i + 1));
+            if (target > i) target = i;
+            unsigned char tmp = p[i];
+            p[i] = p[target];
+            p[target] = tmp;
+        }
+    }
+}
+
 namespace rt {
 static thread_local Arena* g_arena = nullptr;
 Arena::Arena() : prev_(g_arena) { g_arena = this; }
@@ -240,6 +266,20 @@ struct Lowerer {
                 img_ix[c->data] = off;
                 r.image_offset = off;
             } else r.image_offset = im->second;
+        } break;
+        case Texture::NOISE: {
+            /* RT_NOISE_TABLE_BYTES at a 4-byte-aligned offset of the byte blob: gradients, then the three permutations */
+            const NoiseTexture* c = static_cast<const NoiseTexture*>(t);
+            r.type = RT_TEX_NOISE;
+            r.colour[0] = c->scale;
+            r.width = RT_NOISE_OCTAVES;
+            while (S.image_bytes.size() & 3u) S.image_bytes.push_back(0);
+            r.image_offset = S.image_bytes.size();
+            const unsigned char* g = reinterpret_cast<const unsigned char*>(&c->ranvec[0][0]);
+            S.image_bytes.insert(S.image_bytes.end(), g, g + sizeof c->ranvec);
+            S.image_bytes.insert(S.image_bytes.end(), c->permX, c->permX + 256);
+            S.image_bytes.insert(S.image_bytes.end(), c->permY, c->permY + 256);
+            S.image_bytes.insert(S.image_bytes.end(), c->permZ, c->permZ + 256);
         } break;
         }
         S.textures[ix] = r;

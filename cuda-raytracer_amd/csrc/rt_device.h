@@ -629,6 +629,45 @@ __device__ __forceinline__ void rebuild(const DScene& S, const DRay& world_ray, 
 }
 
 /* --------------------------------------------------------------- textures ---- */
+/* Perlin gradient noise with Hermite-smoothed trilinear weights and its turbulence sum ("The Next Week"
+ * ch. 5: perlin::noise, perlin_interp, perlin::turb); the reference has no noise class, the oracle's
+ * noise_turb is the same arithmetic.  `tab` = float gradient[256][3] then three 256-byte permutations. */
+__device__ inline float noise_at(const uint8_t* tab, V3 p)
+{
+    const float* grad = reinterpret_cast<const float*>(tab);
+    const uint8_t* perm = tab + 256 * 3 * 4;
+    const float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    const float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    const float lim = 2147483648.f;
+    const int i = (fx >= -lim && fx < lim) ? (int)fx : 0;
+    const int j = (fy >= -lim && fy < lim) ? (int)fy : 0;
+    const int k = (fz >= -lim && fz < lim) ? (int)fz : 0;
+    const float uu = u * u * (3 - 2 * u), vv = v * v * (3 - 2 * v), ww = w * w * (3 - 2 * w);
+    float accum = 0;
+#pragma unroll
+    for (int di = 0; di < 2; ++di)
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+            for (int dk = 0; dk < 2; ++dk) {
+                const int h = perm[(i + di) & 255] ^ perm[256 + ((j + dj) & 255)] ^ perm[512 + ((k + dk) & 255)];
+                const V3 c = mk(grad[3 * h], grad[3 * h + 1], grad[3 * h + 2]);
+                const V3 wv = mk(u - di, v - dj, w - dk);
+                accum += (di * uu + (1 - di) * (1 - uu)) * (dj * vv + (1 - dj) * (1 - vv)) * (dk * ww + (1 - dk) * (1 - ww)) * dot(c, wv);
+            }
+    return accum;
+}
+__device__ inline float noise_turb(const uint8_t* tab, V3 p, int depth)
+{
+    float accum = 0, weight = 1.f;
+    for (int i = 0; i < depth; ++i) {
+        accum += weight * noise_at(tab, p);
+        weight *= 0.5f;
+        p = 2.f * p;
+    }
+    return fabsf(accum);
+}
+
 template <uint32_t F>
 __device__ __forceinline__ V3 texture_value(const DScene& S, int ti, float u, float v, V3 p)
 {
@@ -650,6 +689,10 @@ __device__ __forceinline__ V3 texture_value(const DScene& S, int ti, float u, fl
         if (j > t.height - 1) j = t.height - 1;
         const uint8_t* px = data + 3 * i + 3 * t.width * j;
         return mk((int)px[0] / 255.f, (int)px[1] / 255.f, (int)px[2] / 255.f);
+    }
+    if ((F & RT_F_NOISE) && t.type == RT_TEX_NOISE) {
+        const float m = 0.5f * (1 + sinf(t.colour[0] * p.z + 10 * noise_turb(S.image + t.image_offset, p, t.width)));
+        return mk(m, m, m);
     }
     return mk(t.colour[0], t.colour[1], t.colour[2]);
 }

@@ -53,6 +53,9 @@ bool rt_validate_scene(const rt_flat_scene* s, std::string& why, int* bvh_depth)
         } else if (t.type == RT_TEX_IMAGE) {
             if (t.width <= 0 || t.height <= 0) return bad("image texture without extent");
             if (t.image_offset + (uint64_t)t.width * (uint64_t)t.height * 3u > s->n_image_bytes) return bad("image texture out of range");
+        } else if (t.type == RT_TEX_NOISE) {
+            if (t.width < 1 || t.width > 16) return bad("noise texture octaves out of range");
+            if ((t.image_offset & 3u) || t.image_offset + RT_NOISE_TABLE_BYTES > s->n_image_bytes) return bad("noise texture table out of range");
         } else if (t.type != RT_TEX_CONSTANT) return bad("unknown texture type");
     }
     for (int i = 0; i < s->n_materials; ++i) {
@@ -341,6 +344,7 @@ uint32_t rt_scene_features(const rt_flat_scene* s)
     for (int i = 0; i < s->n_textures; ++i) {
         if (s->textures[i].type == RT_TEX_CHECKER) f |= RT_F_CHECKER;
         if (s->textures[i].type == RT_TEX_IMAGE) f |= RT_F_IMAGE;
+        if (s->textures[i].type == RT_TEX_NOISE) f |= RT_F_NOISE;
     }
     if (s->camera.lens_radius != 0.f) f |= RT_F_LENS;
     return f;

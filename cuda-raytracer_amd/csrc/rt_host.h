@@ -65,7 +65,9 @@ enum {
     RT_F_CHECKER = 1u << 12,
     RT_F_IMAGE = 1u << 13,
     RT_F_XFORM = 1u << 14,   /* any wrapper op at all */
-    RT_F_ALL = (1u << 15) - 1
+    RT_F_ALL = (1u << 15) - 1,   /* everything the reference's classes can express */
+    RT_F_NOISE = 1u << 15    /* a NoiseTexture (not in the reference; kept out of RT_F_ALL so the kernels
+                                for reference scenes do not carry it) */
 };
 
 /* 4-wide node for the wavefront intersect kernel, 128 bytes: the boxes of up to four children (binary

@@ -28,6 +28,7 @@
 #define RT_V_PLANAR_MEDIA (RT_F_PLANAR | RT_F_XFORM | RT_F_MEDIA | RT_F_ISO)           /* Cornell smoke */
 #define RT_V_LIST         (RT_F_ALL & ~RT_F_BVH)                                       /* any scene without a BVH */
 #define RT_V_BVH_TRI      (RT_F_BVH | RT_F_TRI | RT_F_PLANAR)                          /* triangle mesh + area light */
+#define RT_V_NOISE        (RT_F_ALL | RT_F_NOISE)                                      /* anything with a NoiseTexture */
 #ifndef RT_WF_AUTO_ITEMS
 #define RT_WF_AUTO_ITEMS 65536
 #endif
@@ -511,7 +512,7 @@ static int wf_run(rt_ctx* c, int w, int h, uint32_t s0, uint32_t s1, uint32_t k0
             wf_reset_kernel<<<1, 1, 0, c->stream>>>(W.count, cur ^ 1);
             unsigned blocks = (known + RT_BLOCK - 1) / RT_BLOCK;
             unsigned iblocks = blocks < 2048u ? blocks : 2048u;
-            wf_intersect_kernel<V><<<dim3(iblocks), RT_BLOCK, lds, c->stream>>>(c->ds, W, cur, k0, k1, c->d_counters);
+            wf_intersect_kernel<(V & ~RT_F_NOISE)><<<dim3(iblocks), RT_BLOCK, lds, c->stream>>>(c->ds, W, cur, k0, k1, c->d_counters);   /* reads no texture */
             if (background == RT_BG_BLACK)
                 wf_logic_kernel<V, RT_BG_BLACK><<<dim3(blocks), RT_BLOCK, 0, c->stream>>>(c->ds, W, cur, w, h, s1, k0, k1, max_depth);
             else
@@ -557,6 +558,7 @@ extern "C" int rt_render_accumulate(rt_ctx* c, int w, int h, uint32_t s0, uint32
     const bool wavefront = c->integrator == RT_INTEGRATOR_WAVEFRONT || (c->integrator == RT_INTEGRATOR_AUTO && c->n_bvh_items >= RT_WF_AUTO_ITEMS && c->stack4 <= WF_LDS_STACK + WF_OVF_STACK);
     if (wavefront) {
         int wrc = (c->features & ~RT_V_BVH_TRI) == 0 ? wf_run<RT_V_BVH_TRI>(c, w, h, s0, s1, k0, k1, max_depth, background, accum)
+                  : (c->features & RT_F_NOISE)       ? wf_run<RT_V_NOISE>(c, w, h, s0, s1, k0, k1, max_depth, background, accum)
                                                      : wf_run<RT_F_ALL>(c, w, h, s0, s1, k0, k1, max_depth, background, accum);
         HIPCHK(hipEventRecord(e1, c->stream));
         c->pending.push_back({e0, e1});
@@ -564,8 +566,8 @@ extern "C" int rt_render_accumulate(rt_ctx* c, int w, int h, uint32_t s0, uint32
     }
     const size_t lds = RT_BLOCK * sizeof(int) + stack_bytes(c);
     /* the smallest compiled feature set that covers the scene */
-    static const uint32_t variants[] = {RT_V_PLANAR, RT_V_PLANAR_MEDIA, RT_V_LIST, RT_V_BVH_TRI, RT_F_ALL};
-    uint32_t pick = RT_F_ALL;
+    static const uint32_t variants[] = {RT_V_PLANAR, RT_V_PLANAR_MEDIA, RT_V_LIST, RT_V_BVH_TRI, RT_F_ALL, RT_V_NOISE};
+    uint32_t pick = RT_V_NOISE;
     for (uint32_t v : variants) if ((c->features & ~v) == 0) { pick = v; break; }
 #define RT_LAUNCH(V, G) render_kernel<V, G><<<grid, RT_BLOCK, lds, c->stream>>>(c->ds, w, h, s0, s1, k0, k1, max_depth, accum, c->d_counters)
 #define RT_LAUNCH_BG(V) { if (background == RT_BG_BLACK) RT_LAUNCH(V, RT_BG_BLACK); else RT_LAUNCH(V, RT_BG_SKY); }
@@ -574,7 +576,8 @@ extern "C" int rt_render_accumulate(rt_ctx* c, int w, int h, uint32_t s0, uint32
     case RT_V_PLANAR_MEDIA: RT_LAUNCH_BG(RT_V_PLANAR_MEDIA) break;
     case RT_V_LIST:         RT_LAUNCH_BG(RT_V_LIST) break;
     case RT_V_BVH_TRI:      RT_LAUNCH_BG(RT_V_BVH_TRI) break;
-    default:                RT_LAUNCH_BG(RT_F_ALL) break;
+    case RT_F_ALL:          RT_LAUNCH_BG(RT_F_ALL) break;
+    default:                RT_LAUNCH_BG(RT_V_NOISE) break;
     }
 #undef RT_LAUNCH_BG
 #undef RT_LAUNCH

@@ -323,9 +323,34 @@ Built kat(int width, int height)
     return b;
 }
 
+/* "The Next Week" ch. 5-6: two marble spheres under a light sphere and a light rect.  Not one of the
+ * reference's scenes (it has no noise class); exercises NoiseTexture under Lambert, Metal and a checker. */
+Built perlin_spheres(int width, int height)
+{
+    curandState rng;
+    curand_init(419, 0, 0, &rng);
+    Texture* marble = new NoiseTexture(4.f, &rng);
+    Texture* fine = new NoiseTexture(11.f, &rng);
+    Texture* mixed = new CheckerTexture(fine, new ConstantTexture(Vector3(.8f, .3f, .2f)));
+    Material* light = new DiffuseLight(new ConstantTexture(Vector3(4, 4, 4)));
+    Hitable** list = ptr_array(8);
+    int i = 0;
+    list[i++] = new Sphere(Vector3(0, -1000, 0), 1000, new Lambert(marble));
+    list[i++] = new Sphere(Vector3(0, 2, 0), 2, new Lambert(marble));
+    list[i++] = new Sphere(Vector3(0, 7, 0), 2, light);
+    list[i++] = new XYRect(3, 5, 1, 3, -2, light);
+    list[i++] = new Sphere(Vector3(2.5f, 1, 3.5f), 1, new Metal(fine, .05f));
+    list[i++] = new Translate(new RotateY(new Box(Vector3(0, 0, 0), Vector3(1.5f, 1.5f, 1.5f), new Lambert(mixed)), 25), Vector3(3, 0, -4.5f));
+    Built b;
+    b.world = new HitableList(list, i);
+    b.cam = look(Vector3(26, 3, 6), Vector3(0, 2, 0), 20.f, width, height, 0.f, 10.f);
+    return b;
+}
+
 Built build_named(const std::string& name, int width, int height, int param, bool& known)
 {
     known = true;
+    if (name == "perlin") return perlin_spheres(width, height);
     if (name == "cornell") return cornell(width, height, false);
     if (name == "cornell_smoke") return cornell(width, height, true);
     if (name == "random_spheres") return random_spheres(width, height);

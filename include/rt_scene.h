@@ -83,8 +83,15 @@ typedef struct rt_material {
 enum rt_tex_type {
     RT_TEX_CONSTANT = 0,  /* Texture.cuh:13-23 */
     RT_TEX_CHECKER  = 1,  /* Texture.cuh:25-37  even/odd are texture indices */
-    RT_TEX_IMAGE    = 2   /* Texture.cuh:39-61  RGB8, 3 bytes per texel     */
+    RT_TEX_IMAGE    = 2,  /* Texture.cuh:39-61  RGB8, 3 bytes per texel     */
+    RT_TEX_NOISE    = 3   /* no counterpart in Texture.cuh: the Perlin marble of "Ray Tracing: The Next Week"
+                             ch. 5, (1,1,1) * 0.5 * (1 + sin(scale*p.z + 10*turb(p, octaves)));
+                             colour[0] = scale, width = octaves, image_offset = 4-byte-aligned offset of an
+                             RT_NOISE_TABLE_BYTES table: float gradient[256][3], then uint8 permX[256],
+                             permY[256], permZ[256] */
 };
+#define RT_NOISE_OCTAVES     7
+#define RT_NOISE_TABLE_BYTES (256 * 3 * 4 + 3 * 256)
 typedef struct rt_texture {
     int32_t  type;
     float    colour[3];

@@ -94,6 +94,8 @@ Texture* build_texture(RefScene& R, int ti)
     switch (t.type) {
     case RT_TEX_CONSTANT: out = new ConstantTexture(Vector3(t.colour[0], t.colour[1], t.colour[2])); break;
     case RT_TEX_CHECKER:  out = new CheckerTexture(build_texture(R, t.even), build_texture(R, t.odd)); break;
+    case RT_TEX_NOISE:    /* the reference has no noise class; geometry vectors do not read textures */
+                          out = new ConstantTexture(Vector3(.5f, .5f, .5f)); break;
     default:              out = new ImageTexture(const_cast<unsigned char*>(R.s->image_bytes + t.image_offset), t.width, t.height); break;
     }
     R.textures[ti] = out;

@@ -451,6 +451,46 @@ static int hit_object(const Ctx* c, int oi, const Ray* r, float tMin, float tMax
 }
 
 /* ------------------------------------------------------------- textures ---- */
+/* RT_TEX_NOISE has no counterpart in the reference (Texture.cuh ends at ImageTexture): this restates
+ * perlin::noise / perlin_interp / perlin::turb of "Ray Tracing: The Next Week" ch. 5.  PARITY UNPINNED:
+ * no reference code or fixture covers it; tests check the HIP path against this and its own properties. */
+static float noise_at(const uint8_t* tab, V3 p)
+{
+    const float* grad = (const float*)tab;
+    const uint8_t* perm = tab + 256 * 3 * 4;
+    const float fx = floorf(p.e[0]), fy = floorf(p.e[1]), fz = floorf(p.e[2]);
+    const float u = p.e[0] - fx, v = p.e[1] - fy, w = p.e[2] - fz;
+    const float lim = 2147483648.f;
+    const int i = (fx >= -lim && fx < lim) ? (int)fx : 0;
+    const int j = (fy >= -lim && fy < lim) ? (int)fy : 0;
+    const int k = (fz >= -lim && fz < lim) ? (int)fz : 0;
+    const float uu = u * u * (3 - 2 * u), vv = v * v * (3 - 2 * v), ww = w * w * (3 - 2 * w);
+    float accum = 0;
+    for (int di = 0; di < 2; ++di)
+        for (int dj = 0; dj < 2; ++dj)
+            for (int dk = 0; dk < 2; ++dk) {
+                const int h = perm[(i + di) & 255] ^ perm[256 + ((j + dj) & 255)] ^ perm[512 + ((k + dk) & 255)];
+                const V3 c = v3(grad[3 * h], grad[3 * h + 1], grad[3 * h + 2]);
+                const V3 wv = v3(u - di, v - dj, w - dk);
+                accum += (di * uu + (1 - di) * (1 - uu)) * (dj * vv + (1 - dj) * (1 - vv)) * (dk * ww + (1 - dk) * (1 - ww)) * vdot(c, wv);
+            }
+    return accum;
+}
+static float noise_turb(const uint8_t* tab, V3 p, int depth)
+{
+    float accum = 0, weight = 1.f;
+    for (int i = 0; i < depth; ++i) {
+        accum += weight * noise_at(tab, p);
+        weight *= 0.5f;
+        p = vscale(2.f, p);
+    }
+    return fabsf(accum);
+}
+float rto_noise_turb(const uint8_t* table, const float p[3], int depth)   /* test hook */
+{
+    return noise_turb(table, v3(p[0], p[1], p[2]), depth);
+}
+
 static V3 texture_value(const rt_flat_scene* s, int ti, float u, float v, V3 p)      /* Texture.cuh */
 {
     const rt_texture* t = &s->textures[ti];
@@ -460,6 +500,10 @@ static V3 texture_value(const rt_flat_scene* s, int ti, float u, float v, V3 p) 
         float sines = sinf(10 * p.e[0]) * sinf(10 * p.e[1]) * sinf(10 * p.e[2]);
         if (sines < 0) return texture_value(s, t->odd, u, v, p);
         else return texture_value(s, t->even, u, v, p);
+    }
+    case RT_TEX_NOISE: {
+        float m = 0.5f * (1 + sinf(t->colour[0] * p.e[2] + 10 * noise_turb(s->image_bytes + t->image_offset, p, t->width)));
+        return v3(m, m, m);
     }
     default: {                                                                        /* :49-61 */
         const uint8_t* data = s->image_bytes + t->image_offset;

@@ -52,6 +52,8 @@ void rto_object_hit(const rt_flat_scene* s, int object, int n, const float* rays
 void rto_trace_primary(const rt_flat_scene* s, int W, int H, float s_off, float t_off, int use_bvh,
                        int32_t* prim, float* t_out);
 void rto_texture_value(const rt_flat_scene* s, int texture, int n, const float* uvp5, float* rgb);
+/* turbulence sum of an RT_TEX_NOISE table (RT_NOISE_TABLE_BYTES) at p */
+float rto_noise_turb(const uint8_t* table, const float p[3], int depth);
 /* xi: per call, xi_stride scripted uniforms consumed in the order the reference's scatter() draws them */
 void rto_scatter(const rt_flat_scene* s, int material, int n, const float* ray_in7, const float* rec_in9,
                  const float* xi, int xi_stride, rto_scatter_out* out);

@@ -117,7 +117,7 @@ def render_gpu(ctx, binding, sc, W, H, s0, s1, seed, depth=100, bg=None, integra
                                                ("kat", 0, 64, 48, 6), ("random_spheres", 0, 48, 32, 4),
                                                ("lit_sphere", 0, 64, 48, 8), ("cornell_cluster", 0, 48, 32, 4),
                                                ("tri_mesh", 4000, 48, 32, 4), ("final", 8, 48, 32, 4),
-                                               ("cornell", 0, 37, 23, 5)])
+                                               ("cornell", 0, 37, 23, 5), ("perlin", 0, 64, 48, 8)])
 @pytest.mark.parametrize("integrator", INTEGRATORS)
 def test_render_equals_oracle_sample_for_sample(binding, oracle, gpu_ctx, name, param, W, H, spp, integrator):
     """same (seed, pixel, sample) -> same path: the accumulation buffers agree pixel for pixel, up to the rare
@@ -212,7 +212,7 @@ def test_converged_image_rmse(binding, oracle_mod, gpu_ctx, name):
     assert rmse <= limit, rmse
 
 
-@pytest.mark.parametrize("name,param", [("cornell", 0), ("cornell_smoke", 0), ("final", 8), ("tri_mesh", 20000)])
+@pytest.mark.parametrize("name,param", [("cornell", 0), ("cornell_smoke", 0), ("final", 8), ("tri_mesh", 20000), ("perlin", 0)])
 def test_integrators_agree(binding, gpu_ctx, name, param):
     """megakernel and wavefront render the same samples: images equal up to the order of the per-pixel sums"""
     import torch

@@ -10,7 +10,7 @@ import pytest
 P_END, P_XFORM, P_RECT, P_SPHERE, P_GENERIC, P_BOX = 0, 1, 2, 3, 4, 5
 F = dict(BVH=1 << 0, GROUPLIST=1 << 1, MEDIA=1 << 2, SPHERE=1 << 3, MSPHERE=1 << 4, TRI=1 << 5, PLANAR=1 << 6,
          LONGCHAIN=1 << 7, LENS=1 << 8, GLASS=1 << 9, METAL=1 << 10, ISO=1 << 11, CHECKER=1 << 12, IMAGE=1 << 13,
-         XFORM=1 << 14)
+         XFORM=1 << 14, NOISE=1 << 15)
 
 
 def program(binding, sc):
@@ -66,7 +66,8 @@ def test_generic_records_and_frames(binding):
     ("tri_mesh", 2000, ["BVH", "TRI", "PLANAR"], ["XFORM", "MEDIA", "SPHERE", "GLASS", "METAL", "LENS"]),
     ("random_spheres", 0, ["BVH", "SPHERE", "MSPHERE", "GLASS", "METAL", "CHECKER", "IMAGE"], ["MEDIA", "TRI", "LENS"]),
     ("lit_sphere", 0, ["SPHERE", "XFORM", "LENS", "IMAGE", "CHECKER"], ["BVH", "PLANAR"]),
-    ("final", 6, ["BVH", "MEDIA", "SPHERE", "MSPHERE", "PLANAR", "XFORM", "GLASS", "METAL", "ISO", "IMAGE"], ["TRI", "LENS"]),
+    ("final", 6, ["BVH", "MEDIA", "SPHERE", "MSPHERE", "PLANAR", "XFORM", "GLASS", "METAL", "ISO", "IMAGE"], ["TRI", "LENS", "NOISE"]),
+    ("perlin", 0, ["NOISE", "SPHERE", "PLANAR", "XFORM", "METAL", "CHECKER"], ["BVH", "MEDIA", "IMAGE", "GLASS"]),
 ])
 def test_feature_bits(binding, name, param, want, dont):
     sc = binding.Scene(name, 64, 64, param)
