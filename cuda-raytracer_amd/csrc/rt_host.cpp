@@ -4,6 +4,7 @@
 #include "rt_host.h"
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "../../include/rt_api.h"
@@ -429,3 +430,121 @@ extern "C" int rt_write_ppm(const char* path, const uint8_t* rgb8, int width, in
     if (!ok) { rt_set_error("rt_write_ppm: short write"); return RT_ERR_ARG; }
     return RT_OK;
 }
+
+/* ---- PNG out, PPM in: the image files either side of the path (main.cu:566-570, 688-697) ------------
+ * The reference writes 8-bit RGB PNG through the vendored stb writer.  This writes the same container with
+ * the pixel rows in stored (uncompressed) deflate blocks: any PNG reader opens it, nothing third-party is
+ * needed, and the bytes are a pure function of the pixels. */
+static uint32_t png_crc(const uint8_t* p, size_t n, uint32_t crc)
+{
+    static uint32_t table[256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        ready = true;
+    }
+    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xffu] ^ (crc >> 8);
+    return crc;
+}
+static void png_be32(std::vector<uint8_t>& v, uint32_t x)
+{
+    for (int s = 24; s >= 0; s -= 8) v.push_back((uint8_t)(x >> s));
+}
+static bool png_chunk(FILE* f, const char type[4], const std::vector<uint8_t>& body)
+{
+    std::vector<uint8_t> head;
+    png_be32(head, (uint32_t)body.size());
+    head.insert(head.end(), type, type + 4);
+    uint32_t crc = png_crc(head.data() + 4, 4, 0xffffffffu);
+    crc = png_crc(body.data(), body.size(), crc) ^ 0xffffffffu;
+    std::vector<uint8_t> tail;
+    png_be32(tail, crc);
+    return std::fwrite(head.data(), 1, 8, f) == 8 && std::fwrite(body.data(), 1, body.size(), f) == body.size() &&
+           std::fwrite(tail.data(), 1, 4, f) == 4;
+}
+
+extern "C" int rt_write_png(const char* path, const uint8_t* rgb8, int width, int height)
+{
+    if (!path || !rgb8 || width <= 0 || height <= 0) { rt_set_error("rt_write_png: bad arguments"); return RT_ERR_ARG; }
+    const size_t row = (size_t)width * 3, raw_n = (row + 1) * (size_t)height;
+    if (raw_n > 0xfff00000u) { rt_set_error("rt_write_png: image too large for one IDAT chunk"); return RT_ERR_UNSUPPORTED; }
+    std::vector<uint8_t> ihdr;
+    png_be32(ihdr, (uint32_t)width);
+    png_be32(ihdr, (uint32_t)height);
+    const uint8_t fmt[5] = {8, 2, 0, 0, 0};           /* 8 bits, colour type 2 = RGB, deflate, filter 0, no interlace */
+    ihdr.insert(ihdr.end(), fmt, fmt + 5);
+    /* zlib stream: header, stored blocks of <= 65535 bytes over (filter byte 0 + row) per row, Adler-32 */
+    std::vector<uint8_t> z;
+    z.reserve(raw_n + raw_n / 65535 * 5 + 16);
+    z.push_back(0x78); z.push_back(0x01);
+    uint32_t a = 1, b = 0;
+    std::vector<uint8_t> raw(raw_n);
+    for (int y = 0; y < height; ++y) {
+        raw[(row + 1) * y] = 0;
+        std::memcpy(&raw[(row + 1) * y + 1], rgb8 + row * y, row);
+    }
+    for (size_t off = 0; off < raw_n;) {
+        const size_t n = raw_n - off < 65535 ? raw_n - off : 65535;
+        z.push_back(off + n == raw_n ? 1 : 0);
+        z.push_back((uint8_t)(n & 0xff)); z.push_back((uint8_t)(n >> 8));
+        z.push_back((uint8_t)(~n & 0xff)); z.push_back((uint8_t)((~n >> 8) & 0xff));
+        z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
+        off += n;
+    }
+    for (size_t i = 0; i < raw_n;) {                  /* Adler-32, reduced every 5552 bytes */
+        const size_t end = raw_n - i < 5552 ? raw_n : i + 5552;
+        for (; i < end; ++i) { a += raw[i]; b += a; }
+        a %= 65521u; b %= 65521u;
+    }
+    png_be32(z, (b << 16) | a);
+    FILE* f = std::fopen(path, "wb");
+    if (!f) { rt_set_error(std::string("rt_write_png: cannot open ") + path); return RT_ERR_ARG; }
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    bool ok = std::fwrite(sig, 1, 8, f) == 8;
+    ok = ok && png_chunk(f, "IHDR", ihdr) && png_chunk(f, "IDAT", z) && png_chunk(f, "IEND", std::vector<uint8_t>());
+    ok = std::fclose(f) == 0 && ok;
+    if (!ok) { rt_set_error("rt_write_png: short write"); return RT_ERR_ARG; }
+    return RT_OK;
+}
+
+/* binary PPM (P6, maxval 255, '#' comments in the header): how an RGB8 texture such as the reference's
+ * earth map (main.cu:566-570 loads a JPEG through stb, out of scope) reaches ImageTexture */
+extern "C" int rt_read_ppm(const char* path, uint8_t** rgb8_out, int* width, int* height)
+{
+    if (!path || !rgb8_out || !width || !height) { rt_set_error("rt_read_ppm: bad arguments"); return RT_ERR_ARG; }
+    *rgb8_out = nullptr; *width = *height = 0;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) { rt_set_error(std::string("rt_read_ppm: cannot open ") + path); return RT_ERR_ARG; }
+    auto token = [&](long& out) {
+        int c = std::fgetc(f);
+        for (;;) {
+            while (c == ' ' || c == '\t' || c == '\n' || c == '\r') c = std::fgetc(f);
+            if (c != '#') break;
+            while (c != '\n' && c != EOF) c = std::fgetc(f);
+        }
+        if (c < '0' || c > '9') return false;
+        out = 0;
+        while (c >= '0' && c <= '9') { out = out * 10 + (c - '0'); if (out > 1000000000L) return false; c = std::fgetc(f); }
+        return c == ' ' || c == '\t' || c == '\n' || c == '\r';     /* exactly one whitespace byte ends a token */
+    };
+    long w = 0, h = 0, maxv = 0;
+    const bool magic = std::fgetc(f) == 'P' && std::fgetc(f) == '6';
+    if (!magic || !token(w) || !token(h) || !token(maxv) || w <= 0 || h <= 0 || maxv != 255 || w > 65536 || h > 65536) {
+        std::fclose(f);
+        rt_set_error("rt_read_ppm: not a binary PPM with maxval 255");
+        return RT_ERR_UNSUPPORTED;
+    }
+    const size_t n = (size_t)w * (size_t)h * 3;
+    uint8_t* px = (uint8_t*)std::malloc(n);
+    if (!px) { std::fclose(f); rt_set_error("rt_read_ppm: out of memory"); return RT_ERR_ARG; }
+    const bool ok = std::fread(px, 1, n, f) == n;
+    std::fclose(f);
+    if (!ok) { std::free(px); rt_set_error("rt_read_ppm: truncated pixel data"); return RT_ERR_ARG; }
+    *rgb8_out = px; *width = (int)w; *height = (int)h;
+    return RT_OK;
+}
+extern "C" void rt_free_pixels(uint8_t* rgb8) { std::free(rgb8); }

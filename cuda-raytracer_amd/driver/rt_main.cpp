@@ -14,8 +14,11 @@
  *   - "# of GPUs" = N shards the SAMPLES over N devices (any N, not only 2) instead of splitting the
  *     image into halves that each rebuild the world (main.cu:128-174, 652-699); the N sums are added on
  *     the host here (bench.py shows the one-process-per-GPU + RCCL form);
- *   - the image is written as binary PPM with values clamped to 0..255 (the reference writes PNG
- *     through the vendored stb writer and lets values above 1 wrap, main.cu:688-697).
+ *   - the image is written as <name>.png like the reference's (main.cu:663,697,707; rt_write_png instead of
+ *     the vendored stb writer) and as <name>.ppm, with values clamped to 0..255 (the reference lets values
+ *     above 1 wrap, main.cu:688-694);
+ *   - the texture handed to the scene function is assets/earthmap.ppm when that file exists (the reference
+ *     decodes assets/earthmap.jpg through stb, main.cu:566-570; neither the asset nor a JPEG decoder is here).
  * Optional argv: a built-in scene name (default "cornell" = the reference's active scene, main.cu:533;
  * "user" = the scene function in this file) and a scene parameter.
  */
@@ -46,7 +49,7 @@ static void check_rt(int rc, const char* what, const char* file, int line)
 
 /* ---- a user's scene, in the reference's form (compare main.cu:278-306): Cornell box with a glass sphere ---- */
 static void userScene(Hitable** dList, Hitable** dWorld, Camera** dCamera, int width, int height,
-                      ImageTexture** /*texture*/, curandState* /*randState*/)
+                      ImageTexture** texture, curandState* /*randState*/)
 {
     int i = 0;
     Material* red = new Lambert(new ConstantTexture(Vector3(.65f, .05f, .05f)));
@@ -61,6 +64,7 @@ static void userScene(Hitable** dList, Hitable** dWorld, Camera** dCamera, int w
     dList[i++] = new FlipNormals(new XYRect(0, 555, 0, 555, 555, white));
     dList[i++] = new Translate(new RotateY(new Box(Vector3(0, 0, 0), Vector3(165, 330, 165), white), 15), Vector3(265, 0, 295));
     dList[i++] = new Sphere(Vector3(190, 90, 190), 90, new Glass(1.5f));
+    if (*texture) dList[i++] = new Sphere(Vector3(420, 60, 120), 60, new Lambert(*texture));   /* main.cu:241 style */
     *dWorld = new HitableList(dList, i);
     *dCamera = new Camera(Vector3(278, 278, -800), Vector3(278, 278, 0), Vector3(0, 1, 0), 40.f,
                           float(width) / float(height), 0.f, 10.f, 0.f, 1.f);
@@ -86,9 +90,13 @@ static std::vector<float> renderShard(int width, int height, int numSamples, int
         curandState rs;
         curand_init(419, 0, 0, &rs);                                       /* main.cu:105 */
         ImageTexture* tex = nullptr;
+        uint8_t* earth = nullptr;
+        int tw = 0, th = 0;
+        if (rt_read_ppm("assets/earthmap.ppm", &earth, &tw, &th) == RT_OK) tex = new ImageTexture(earth, tw, th);
         userScene(dList.data(), &world, &cam, width, height, &tex, &rs);
         std::string err;
         if (!rt::lower(world, cam, rt::LowerOptions(), flat, err)) { std::cerr << "lowering failed: " << err << "\n"; std::exit(99); }
+        rt_free_pixels(earth);          /* the flat scene holds its own copy */
         view = &flat.view;
     } else {
         checkRt(rt_scene_create_builtin(g_scene.c_str(), width, height, g_param, &scene));
@@ -157,8 +165,8 @@ int main(int argc, char** argv)
         for (size_t i = 0; i < sum.size(); ++i) sum[i] += part[i];
     }
     const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    std::string fileName = numGPUs > 1 ? "output/multiGPUTesting" : "output/singleGPUTesting";
-    fileName += ".ppm";
+    const std::string stem = numGPUs > 1 ? "output/multiGPUTesting" : "output/singleGPUTesting";
+    const std::string fileName = stem + ".png";
     std::cerr << "\nRendered in " << elapsed << " seconds to " << fileName << std::endl;
 
     /* mean, gamma 2 (main.cu:192-196), row flip + quantise (main.cu:668-697) */
@@ -167,6 +175,7 @@ int main(int argc, char** argv)
     std::vector<uint8_t> pixels((size_t)width * height * 3);
     checkRt(rt_quantise_rgb8(sum.data(), width, height, pixels.data()));
     (void)mkdir("output", 0777);
-    checkRt(rt_write_ppm(fileName.c_str(), pixels.data(), width, height));
+    checkRt(rt_write_png(fileName.c_str(), pixels.data(), width, height));
+    checkRt(rt_write_ppm((stem + ".ppm").c_str(), pixels.data(), width, height));
     return 0;
 }

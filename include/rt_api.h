@@ -133,6 +133,15 @@ int  rt_flat_bvh_stats(const rt_flat_scene* flat, int* nodes2, int* depth2, int*
  * 0..255 (the reference does not clamp and wraps above 1).  out is W*H*3 bytes. */
 int  rt_quantise_rgb8(const float* rgb, int width, int height, uint8_t* out);
 int  rt_write_ppm(const char* path, const uint8_t* rgb8, int width, int height);
+/* 8-bit RGB PNG, the format main() writes through stbi_write_png (main.cu:697, writeImage.h); rows are
+ * stored uncompressed, so the file is a pure function of the pixels and needs no third-party code */
+int  rt_write_png(const char* path, const uint8_t* rgb8, int width, int height);
+
+/* ---- texture input (stands where main.cu:566-570 calls stbi_load on a JPEG; stb is out of scope) ---- */
+/* binary PPM (P6, maxval 255) -> malloc'ed W*H*3 RGB8, top row first: what ImageTexture(pixels, w, h)
+ * (Texture.cuh:45) takes.  Free with rt_free_pixels. */
+int  rt_read_ppm(const char* path, uint8_t** rgb8_out, int* width, int* height);
+void rt_free_pixels(uint8_t* rgb8);
 
 #ifdef __cplusplus
 }

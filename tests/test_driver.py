@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import ROOT
+from test_image_io import decode_png
 
 EXE = os.path.join(ROOT, "cuda-raytracer_amd", "rt_render")
 
@@ -36,6 +37,8 @@ def test_prompts_and_image(binding, gpu_ctx, tmp_path):
     assert r.stdout == "Width: Height: Number of Samples: # of GPUs: "          # main.cu:630-640
     assert "Rendering a 64x48 image with 1 GPU" in r.stderr and "Rendered in" in r.stderr
     img = read_ppm(tmp_path / "output" / "singleGPUTesting.ppm")
+    assert "to output/singleGPUTesting.png" in r.stderr                          # main.cu:663,707
+    assert np.array_equal(decode_png(open(tmp_path / "output" / "singleGPUTesting.png", "rb").read()), img)
     # the same render through the ABI: seed 419, samples [0, spp), depth 100, gamma 2, top row first
     sc = binding.Scene("cornell", W, H)
     gpu_ctx.upload(sc)
@@ -54,6 +57,14 @@ def test_user_scene_and_bad_input(tmp_path):
     assert r.returncode == 0, r.stderr
     img = read_ppm(tmp_path / "output" / "singleGPUTesting.ppm")
     assert img.shape == (32, 48, 3) and img.max() > 0
+    # with assets/earthmap.ppm beside it the scene function is handed an ImageTexture (main.cu:566-574) and the image changes
+    (tmp_path / "assets").mkdir()
+    tex = np.random.default_rng(1).integers(0, 256, (16, 32, 3), dtype=np.uint8)
+    (tmp_path / "assets" / "earthmap.ppm").write_bytes(b"P6\n32 16\n255\n" + tex.tobytes())
+    r = run_driver(tmp_path, "48\n32\n4\n1\n", "user")
+    assert r.returncode == 0, r.stderr
+    img2 = read_ppm(tmp_path / "output" / "singleGPUTesting.ppm")
+    assert img2.shape == img.shape and not np.array_equal(img, img2)
     r = run_driver(tmp_path, "0\n32\n4\n1\n")
     assert r.returncode == 1
     r = run_driver(tmp_path, "16\n16\n1\n1\n", "no_such_scene")
