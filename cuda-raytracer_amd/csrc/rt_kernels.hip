@@ -12,6 +12,9 @@
  * by its own queue traffic there.
  */
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -596,6 +599,76 @@ extern "C" int rt_resolve(rt_ctx* c, const float* accum, int w, int h, uint32_t 
     float inv = 1.0f / float(spp);
     resolve_kernel<<<dim3((unsigned)((n + RT_BLOCK - 1) / RT_BLOCK)), RT_BLOCK, 0, c->stream>>>(accum, n, inv, gamma, rgb);
     HIPCHK(hipGetLastError());
+    return RT_OK;
+}
+
+/* ---- RCCL reduce of per-GPU accumulation buffers ------------------------------------------------------
+ * librccl.so is opened on first use (a single-GPU process never pays for it); types come from <rccl/rccl.h>. */
+namespace {
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::vector<int> devices;          /* the device list the cached communicators were made for */
+    std::vector<ncclComm_t> comms;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mutex;
+
+int rccl_load()
+{
+    if (g_rccl.handle) return RT_OK;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) { rt_set_error(std::string("rt_reduce_accum: cannot load librccl: ") + dlerror()); return RT_ERR_RCCL; }
+    bool ok = true;
+    auto sym = [&](const char* name) { void* p = dlsym(h, name); if (!p) ok = false; return p; };
+    g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))sym("ncclCommInitAll");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+    g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
+    g_rccl.Reduce = (decltype(g_rccl.Reduce))sym("ncclReduce");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+    if (!ok) { dlclose(h); rt_set_error("rt_reduce_accum: librccl lacks an expected symbol"); return RT_ERR_RCCL; }
+    g_rccl.handle = h;
+    return RT_OK;
+}
+#define RCCLCHK(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { \
+    rt_set_error(std::string(#call) + ": " + g_rccl.GetErrorString(r_)); return RT_ERR_RCCL; } } while (0)
+}  // namespace
+
+extern "C" int rt_reduce_accum(rt_ctx* const* ctxs, float* const* accum, int n, uint64_t count, int root)
+{
+    if (!ctxs || !accum || n < 1 || root < 0 || root >= n || count == 0) { rt_set_error("rt_reduce_accum: bad arguments"); return RT_ERR_ARG; }
+    std::vector<int> devices(n);
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i] || !accum[i]) { rt_set_error("rt_reduce_accum: null context or buffer"); return RT_ERR_ARG; }
+        devices[i] = ctxs[i]->device;
+        for (int j = 0; j < i; ++j)
+            if (devices[j] == devices[i]) { rt_set_error("rt_reduce_accum: two contexts on one device"); return RT_ERR_ARG; }
+    }
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    int rc = rccl_load();
+    if (rc) return rc;
+    if (g_rccl.devices != devices) {
+        for (ncclComm_t c : g_rccl.comms) (void)g_rccl.CommDestroy(c);
+        g_rccl.comms.assign(n, nullptr);
+        g_rccl.devices.clear();
+        RCCLCHK(g_rccl.CommInitAll(g_rccl.comms.data(), n, devices.data()));
+        g_rccl.devices = devices;
+    }
+    /* rank i = position i in the lists; in place: the root's buffer receives the sum */
+    RCCLCHK(g_rccl.GroupStart());
+    for (int i = 0; i < n; ++i) {
+        HIPCHK(hipSetDevice(devices[i]));
+        ncclResult_t r = g_rccl.Reduce(accum[i], accum[i], (size_t)count, ncclFloat, ncclSum, root, g_rccl.comms[i], ctxs[i]->stream);
+        if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); rt_set_error(std::string("ncclReduce: ") + g_rccl.GetErrorString(r)); return RT_ERR_RCCL; }
+    }
+    RCCLCHK(g_rccl.GroupEnd());
     return RT_OK;
 }
 

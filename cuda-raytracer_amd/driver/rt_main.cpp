@@ -12,8 +12,8 @@
  *     flattens what it built, and nothing is built inside a kernel (main.cu:527-539);
  *   - gpuRender() is a few calls on the C ABI (include/rt_api.h);
  *   - "# of GPUs" = N shards the SAMPLES over N devices (any N, not only 2) instead of splitting the
- *     image into halves that each rebuild the world (main.cu:128-174, 652-699); the N sums are added on
- *     the host here (bench.py shows the one-process-per-GPU + RCCL form);
+ *     image into halves that each rebuild the world (main.cu:128-174, 652-699); the N sums are added onto
+ *     GPU 0 by rt_reduce_accum (RCCL over xGMI; bench.py shows the one-process-per-GPU form of the same);
  *   - the image is written as <name>.png like the reference's (main.cu:663,697,707; rt_write_png instead of
  *     the vendored stb writer) and as <name>.ppm, with values clamped to 0..255 (the reference lets values
  *     above 1 wrap, main.cu:688-694);
@@ -74,11 +74,18 @@ static std::string g_scene = "cornell";
 static int g_param = 0;
 static int g_shards = 1;
 
-/* replaces gpuRender (main.cu:553-620).  Returns W*H linear radiance SUMS (not yet averaged) of this
- * device's share of the samples; gpuId = shard index = device index. */
-static std::vector<float> renderShard(int width, int height, int numSamples, int gpuId)
-{
+/* one device's share of the render: its context, its W*H*3 buffer of linear radiance SUMS (not yet averaged) */
+struct Shard {
+    rt_ctx* ctx = nullptr;
     rt_scene* scene = nullptr;
+    float* accum = nullptr;     /* device memory */
+};
+
+/* replaces gpuRender (main.cu:553-620): renders this device's share of the samples into its own buffer and
+ * returns with the work enqueued and finished; gpuId = shard index = device index. */
+static Shard renderShard(int width, int height, int numSamples, int gpuId)
+{
+    Shard sh;
     int background = RT_BG_BLACK;
     rt::FlatScene flat;                 /* storage of a user scene; unused for built-ins */
     const rt_flat_scene* view = nullptr;
@@ -99,34 +106,27 @@ static std::vector<float> renderShard(int width, int height, int numSamples, int
         rt_free_pixels(earth);          /* the flat scene holds its own copy */
         view = &flat.view;
     } else {
-        checkRt(rt_scene_create_builtin(g_scene.c_str(), width, height, g_param, &scene));
-        view = rt_scene_flat(scene);
-        background = rt_scene_default_background(scene);
+        checkRt(rt_scene_create_builtin(g_scene.c_str(), width, height, g_param, &sh.scene));
+        view = rt_scene_flat(sh.scene);
+        background = rt_scene_default_background(sh.scene);
     }
-    rt_ctx* ctx = nullptr;
-    checkRt(rt_ctx_create(gpuId, nullptr, &ctx));
-    checkRt(rt_scene_upload(ctx, view));
+    checkRt(rt_ctx_create(gpuId, nullptr, &sh.ctx));
+    checkRt(rt_scene_upload(sh.ctx, view));
     const size_t n = (size_t)width * height * 3;
-    float* accum = nullptr;
     checkHip(hipSetDevice(gpuId));
-    checkHip(hipMalloc((void**)&accum, n * sizeof(float)));
-    checkHip(hipMemset(accum, 0, n * sizeof(float)));
+    checkHip(hipMalloc((void**)&sh.accum, n * sizeof(float)));
+    checkHip(hipMemset(sh.accum, 0, n * sizeof(float)));
     checkHip(hipDeviceSynchronize());      /* the context renders on a stream of its own */
     /* this shard's samples: [s0, s1) of the global range, so that N shards together render numSamples */
     const uint32_t s0 = (uint32_t)((long long)numSamples * gpuId / g_shards);
     const uint32_t s1 = (uint32_t)((long long)numSamples * (gpuId + 1) / g_shards);
-    checkRt(rt_render_accumulate(ctx, width, height, s0, s1, /*seed*/419, /*depth*/100, background, accum));
-    checkRt(rt_synchronize(ctx));
-    std::vector<float> host(n);
-    checkHip(hipMemcpy(host.data(), accum, n * sizeof(float), hipMemcpyDeviceToHost));
+    checkRt(rt_render_accumulate(sh.ctx, width, height, s0, s1, /*seed*/419, /*depth*/100, background, sh.accum));
+    checkRt(rt_synchronize(sh.ctx));
     rt_counters c;
-    checkRt(rt_get_counters(ctx, &c));
+    checkRt(rt_get_counters(sh.ctx, &c));
     std::cerr << "GPU " << gpuId << ": samples [" << s0 << "," << s1 << "), " << c.rays << " rays in " << c.render_ms << " ms = "
               << (c.render_ms > 0 ? c.rays / c.render_ms / 1e3 : 0.0) << " Mrays/s\n";
-    checkHip(hipFree(accum));
-    rt_ctx_destroy(ctx);
-    if (scene) rt_scene_destroy(scene);
-    return host;
+    return sh;
 }
 
 int main(int argc, char** argv)
@@ -157,12 +157,26 @@ int main(int argc, char** argv)
     std::cerr << "\nRender initiated on " << ctime(&now) << std::endl;
 
     const auto t0 = std::chrono::steady_clock::now();
-    std::vector<std::future<std::vector<float>>> jobs;
+    std::vector<std::future<Shard>> jobs;                                      /* one host thread per GPU, main.cu:655-656 */
     for (int g = 0; g < numGPUs; ++g) jobs.push_back(std::async(std::launch::async, &renderShard, width, height, numSamples, g));
-    std::vector<float> sum = jobs[0].get();
-    for (int g = 1; g < numGPUs; ++g) {
-        std::vector<float> part = jobs[g].get();
-        for (size_t i = 0; i < sum.size(); ++i) sum[i] += part[i];
+    std::vector<Shard> shards;
+    for (auto& j : jobs) shards.push_back(j.get());
+    const size_t n = (size_t)width * height * 3;
+    if (numGPUs > 1) {                                                         /* RCCL reduce over xGMI onto GPU 0 */
+        std::vector<rt_ctx*> ctxs;
+        std::vector<float*> bufs;
+        for (Shard& sh : shards) { ctxs.push_back(sh.ctx); bufs.push_back(sh.accum); }
+        checkRt(rt_reduce_accum(ctxs.data(), bufs.data(), numGPUs, n, 0));
+        for (Shard& sh : shards) checkRt(rt_synchronize(sh.ctx));
+    }
+    std::vector<float> sum(n);
+    checkHip(hipSetDevice(0));
+    checkHip(hipMemcpy(sum.data(), shards[0].accum, n * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t g = 0; g < shards.size(); ++g) {
+        checkHip(hipSetDevice((int)g));
+        checkHip(hipFree(shards[g].accum));
+        rt_ctx_destroy(shards[g].ctx);
+        if (shards[g].scene) rt_scene_destroy(shards[g].scene);
     }
     const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const std::string stem = numGPUs > 1 ? "output/multiGPUTesting" : "output/singleGPUTesting";

@@ -29,7 +29,8 @@ enum rt_status {
     RT_ERR_ARG       = -1,   /* bad argument / scene fails validation */
     RT_ERR_HIP       = -2,   /* a HIP runtime call failed */
     RT_ERR_UNSUPPORTED = -3, /* scene graph the flat tables cannot express */
-    RT_ERR_NO_SCENE  = -4
+    RT_ERR_NO_SCENE  = -4,
+    RT_ERR_RCCL      = -5    /* librccl could not be loaded, or an RCCL call failed */
 };
 
 typedef struct rt_ctx   rt_ctx;
@@ -114,6 +115,13 @@ int  rt_ctx_set_integrator(rt_ctx* c, int mode);
 /* rgb_dev = gamma ? sqrtf(accum/spp) : accum/spp   (main.cu:192-196).  Asynchronous. */
 int  rt_resolve(rt_ctx* c, const float* accum_dev, int width, int height, uint32_t spp, int gamma,
                 float* rgb_dev);
+/* Multi-GPU exchange step: adds the n accumulation buffers (accum_dev[i] on ctxs[i]'s device, `count` floats
+ * each, normally 3*W*H) into accum_dev[root] with one RCCL ncclReduce per device over xGMI, enqueued on each
+ * context's stream; the other buffers are left as they were.  Contexts must sit on n different devices of
+ * this process.  Replaces the host-side stitch of the two half images (main.cu:711-730).  librccl is loaded
+ * on the first call, not when this library is loaded; communicators are kept for the next call over the same
+ * devices.  One process per GPU (bench.py) does the same through torch.distributed instead. */
+int  rt_reduce_accum(rt_ctx* const* ctxs, float* const* accum_dev, int n, uint64_t count, int root);
 int  rt_synchronize(rt_ctx* c);
 int  rt_get_counters(rt_ctx* c, rt_counters* out);   /* synchronizes first */
 int  rt_reset_counters(rt_ctx* c);
