@@ -452,6 +452,14 @@ extern "C" int rt_trace_primary(rt_ctx* c, int w, int h, float s_off, float t_of
     return RT_OK;
 }
 
+static int drain_events(rt_ctx* c, size_t keep_newest = 0);
+/* a caller that renders forever without reading the counters must not pile up events */
+static int note_render(rt_ctx* c, hipEvent_t e0, hipEvent_t e1)
+{
+    c->pending.push_back({e0, e1});
+    return c->pending.size() > 64 ? drain_events(c, 32) : RT_OK;
+}
+
 /* ------------------------------------------------------------ wavefront host -- */
 __global__ void wf_reset_kernel(uint32_t* count, int which) { count[which] = 0u; count[2] = 0u; }
 
@@ -564,8 +572,8 @@ extern "C" int rt_render_accumulate(rt_ctx* c, int w, int h, uint32_t s0, uint32
                   : (c->features & RT_F_NOISE)       ? wf_run<RT_V_NOISE>(c, w, h, s0, s1, k0, k1, max_depth, background, accum)
                                                      : wf_run<RT_F_ALL>(c, w, h, s0, s1, k0, k1, max_depth, background, accum);
         HIPCHK(hipEventRecord(e1, c->stream));
-        c->pending.push_back({e0, e1});
-        return wrc;
+        int nrc = note_render(c, e0, e1);
+        return wrc ? wrc : nrc;
     }
     const size_t lds = RT_BLOCK * sizeof(int) + stack_bytes(c);
     /* the smallest compiled feature set that covers the scene */
@@ -586,9 +594,9 @@ extern "C" int rt_render_accumulate(rt_ctx* c, int w, int h, uint32_t s0, uint32
 #undef RT_LAUNCH
     hipError_t le = hipGetLastError();
     HIPCHK(hipEventRecord(e1, c->stream));
-    c->pending.push_back({e0, e1});
+    int nrc = note_render(c, e0, e1);
     if (le != hipSuccess) { rt_set_error(std::string("render launch failed: ") + hipGetErrorString(le)); return RT_ERR_HIP; }
-    return RT_OK;
+    return nrc;
 }
 
 extern "C" int rt_resolve(rt_ctx* c, const float* accum, int w, int h, uint32_t spp, int gamma, float* rgb)
@@ -680,8 +688,24 @@ extern "C" int rt_synchronize(rt_ctx* c)
     return RT_OK;
 }
 
-static int drain_events(rt_ctx* c)
+/* folds the event pairs of finished renders into the timing totals; keep_newest > 0 leaves that many pairs pending */
+static int drain_events(rt_ctx* c, size_t keep_newest)
 {
+    if (keep_newest) {
+        while (c->pending.size() > keep_newest) {
+            auto p = c->pending.front();
+            float ms = 0.f;
+            HIPCHK(hipEventSynchronize(p.second));
+            HIPCHK(hipEventElapsedTime(&ms, p.first, p.second));
+            c->render_ms += ms;
+            c->last_ms = ms;
+            c->launches++;
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+            c->pending.erase(c->pending.begin());
+        }
+        return RT_OK;
+    }
     for (auto& p : c->pending) {
         float ms = 0.f;
         HIPCHK(hipEventSynchronize(p.second));
@@ -732,7 +756,8 @@ extern "C" int rt_reset_counters(rt_ctx* c)
     HIPCHK(hipStreamSynchronize(c->stream));
     int rc = drain_events(c);
     if (rc) return rc;
-    HIPCHK(hipMemset(c->d_counters, 0, RT_N_COUNTERS * sizeof(unsigned long long)));
+    /* on the context's own stream: it may be non-blocking, and a null-stream memset would not be ordered with the next render */
+    HIPCHK(hipMemsetAsync(c->d_counters, 0, RT_N_COUNTERS * sizeof(unsigned long long), c->stream));
     c->render_ms = c->last_ms = 0.0;
     c->launches = 0;
     return RT_OK;

@@ -351,3 +351,23 @@ def test_edge_cases(binding, gpu_ctx):
         fresh.render_accumulate(acc, W, H, 0, 1, 1, 100, 0)
     assert "no scene" in str(e.value)
     fresh.close()
+
+
+def test_many_renders_between_counter_reads(binding, gpu_ctx):
+    """timing events of finished renders are folded in as the calls go; nothing is lost when the caller reads the
+    counters only at the end"""
+    import torch
+    W, H, calls = 16, 16, 150
+    sc = binding.Scene("cornell", W, H)
+    gpu_ctx.upload(sc)
+    gpu_ctx.reset_counters()
+    acc = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for i in range(calls):
+        gpu_ctx.render_accumulate(acc, W, H, i, i + 1, 419, 100, sc.background)
+    c = gpu_ctx.counters()
+    assert c.render_launches == calls and c.samples == calls * W * H and c.render_ms > 0
+    gpu_ctx.reset_counters()
+    gpu_ctx.render_accumulate(acc, W, H, 0, 1, 419, 100, sc.background)      # ordered after the reset
+    c = gpu_ctx.counters()
+    assert c.render_launches == 1 and c.samples == W * H
