@@ -20,13 +20,20 @@
  *   - the texture handed to the scene function is assets/earthmap.ppm when that file exists (the reference
  *     decodes assets/earthmap.jpg through stb, main.cu:566-570; neither the asset nor a JPEG decoder is here).
  * Optional argv: a built-in scene name (default "cornell" = the reference's active scene, main.cu:533;
- * "user" = the scene function in this file) and a scene parameter.
+ * "user" = the scene function in this file) and a scene parameter; and, with no counterpart in the reference
+ * (progressive rendering):
+ *   --chunk N          render N samples per call instead of all at once
+ *   --checkpoint FILE  after every chunk write the sums so far (one GPU only); the file is replaced atomically
+ *   --resume FILE      start from such a file; width, height, sample count and scene must be the same
+ *   --stop-at N        leave after sample N with the checkpoint written and no image (an interrupted run)
+ * A resumed run ends with bit for bit the image of the uninterrupted run with the same --chunk.
  */
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <ctime>
 #include <future>
 #include <iostream>
@@ -73,6 +80,41 @@ static void userScene(Hitable** dList, Hitable** dWorld, Camera** dCamera, int w
 static std::string g_scene = "cornell";
 static int g_param = 0;
 static int g_shards = 1;
+static int g_chunk = 0, g_stop_at = 0;
+static std::string g_checkpoint, g_resume;
+
+/* checkpoint file: this header, then width*height*3 float sums (row 0 = bottom) */
+struct CheckpointHeader {
+    char magic[8];              /* "RTACCUM1" */
+    int32_t width, height;
+    uint32_t samples_done, samples_total;
+    uint64_t seed;
+    char scene[32];
+    int32_t param, pad;
+};
+
+static bool writeCheckpoint(const std::string& path, const CheckpointHeader& h, const std::vector<float>& sums)
+{
+    const std::string tmp = path + ".tmp";
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    bool ok = std::fwrite(&h, sizeof h, 1, f) == 1 && std::fwrite(sums.data(), sizeof(float), sums.size(), f) == sums.size();
+    ok = std::fclose(f) == 0 && ok;
+    return ok && std::rename(tmp.c_str(), path.c_str()) == 0;
+}
+static bool readCheckpoint(const std::string& path, CheckpointHeader& h, std::vector<float>& sums)
+{
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, "RTACCUM1", 8) == 0 && h.width > 0 && h.height > 0 &&
+              (long long)h.width * h.height <= (1ll << 30);
+    if (ok) {
+        sums.resize((size_t)h.width * h.height * 3);
+        ok = std::fread(sums.data(), sizeof(float), sums.size(), f) == sums.size() && std::fgetc(f) == EOF;
+    }
+    std::fclose(f);
+    return ok;
+}
 
 /* one device's share of the render: its context, its W*H*3 buffer of linear radiance SUMS (not yet averaged) */
 struct Shard {
@@ -116,12 +158,42 @@ static Shard renderShard(int width, int height, int numSamples, int gpuId)
     checkHip(hipSetDevice(gpuId));
     checkHip(hipMalloc((void**)&sh.accum, n * sizeof(float)));
     checkHip(hipMemset(sh.accum, 0, n * sizeof(float)));
-    checkHip(hipDeviceSynchronize());      /* the context renders on a stream of its own */
     /* this shard's samples: [s0, s1) of the global range, so that N shards together render numSamples */
-    const uint32_t s0 = (uint32_t)((long long)numSamples * gpuId / g_shards);
-    const uint32_t s1 = (uint32_t)((long long)numSamples * (gpuId + 1) / g_shards);
-    checkRt(rt_render_accumulate(sh.ctx, width, height, s0, s1, /*seed*/419, /*depth*/100, background, sh.accum));
-    checkRt(rt_synchronize(sh.ctx));
+    uint32_t s0 = (uint32_t)((long long)numSamples * gpuId / g_shards);
+    uint32_t s1 = (uint32_t)((long long)numSamples * (gpuId + 1) / g_shards);
+    CheckpointHeader ck;
+    std::memset(&ck, 0, sizeof ck);
+    std::memcpy(ck.magic, "RTACCUM1", 8);
+    ck.width = width; ck.height = height; ck.samples_total = (uint32_t)numSamples; ck.seed = 419; ck.param = g_param;
+    std::strncpy(ck.scene, g_scene.c_str(), sizeof ck.scene - 1);
+    std::vector<float> host;
+    if (!g_resume.empty()) {
+        CheckpointHeader old;
+        if (!readCheckpoint(g_resume, old, host)) { std::cerr << "cannot read checkpoint " << g_resume << "\n"; std::exit(1); }
+        if (old.width != width || old.height != height || old.samples_total != ck.samples_total || old.seed != ck.seed ||
+            old.param != ck.param || std::strncmp(old.scene, ck.scene, sizeof ck.scene) != 0 || old.samples_done > ck.samples_total) {
+            std::cerr << "checkpoint " << g_resume << " belongs to another render\n";
+            std::exit(1);
+        }
+        checkHip(hipMemcpy(sh.accum, host.data(), n * sizeof(float), hipMemcpyHostToDevice));
+        s0 = old.samples_done;
+        std::cerr << "resuming at sample " << s0 << "\n";
+    }
+    checkHip(hipDeviceSynchronize());      /* the context renders on a stream of its own */
+    if (g_stop_at > 0 && (uint32_t)g_stop_at < s1) s1 = (uint32_t)g_stop_at;
+    const uint32_t chunk = g_chunk > 0 ? (uint32_t)g_chunk : (s1 > s0 ? s1 - s0 : 1u);
+    for (uint32_t s = s0; s < s1; s += chunk) {
+        const uint32_t e = s1 - s < chunk ? s1 : s + chunk;
+        checkRt(rt_render_accumulate(sh.ctx, width, height, s, e, /*seed*/419, /*depth*/100, background, sh.accum));
+        checkRt(rt_synchronize(sh.ctx));
+        if (!g_checkpoint.empty()) {
+            host.resize(n);
+            checkHip(hipMemcpy(host.data(), sh.accum, n * sizeof(float), hipMemcpyDeviceToHost));
+            ck.samples_done = e;
+            if (!writeCheckpoint(g_checkpoint, ck, host)) { std::cerr << "cannot write checkpoint " << g_checkpoint << "\n"; std::exit(1); }
+        }
+        if (g_chunk > 0) std::cerr << "samples " << e << " / " << numSamples << "\n";
+    }
     rt_counters c;
     checkRt(rt_get_counters(sh.ctx, &c));
     std::cerr << "GPU " << gpuId << ": samples [" << s0 << "," << s1 << "), " << c.rays << " rays in " << c.render_ms << " ms = "
@@ -131,8 +203,20 @@ static Shard renderShard(int width, int height, int numSamples, int gpuId)
 
 int main(int argc, char** argv)
 {
-    if (argc > 1) g_scene = argv[1];
-    if (argc > 2) g_param = std::atoi(argv[2]);
+    int positional = 0;
+    for (int a = 1; a < argc; ++a) {
+        const std::string arg = argv[a];
+        const bool has_value = a + 1 < argc;
+        if (arg == "--chunk" && has_value) g_chunk = std::atoi(argv[++a]);
+        else if (arg == "--stop-at" && has_value) g_stop_at = std::atoi(argv[++a]);
+        else if (arg == "--checkpoint" && has_value) g_checkpoint = argv[++a];
+        else if (arg == "--resume" && has_value) g_resume = argv[++a];
+        else if (arg.rfind("--", 0) == 0) { std::cerr << "unknown or incomplete option " << arg << "\n"; return 1; }
+        else if (positional == 0) { g_scene = arg; ++positional; }
+        else if (positional == 1) { g_param = std::atoi(arg.c_str()); ++positional; }
+        else { std::cerr << "too many arguments\n"; return 1; }
+    }
+    if (g_chunk < 0 || g_stop_at < 0) { std::cerr << "bad option value\n"; return 1; }
     std::cout << "Width: ";
     int width = 0;
     std::cin >> width;
@@ -151,6 +235,10 @@ int main(int argc, char** argv)
     if (numGPUs < 1) numGPUs = 1;
     if (numGPUs > visible) { std::cerr << "only " << visible << " GPU(s) visible\n"; numGPUs = visible > 0 ? visible : 1; }
     if (numGPUs > numSamples) numGPUs = numSamples;
+    if (numGPUs > 1 && (!g_checkpoint.empty() || !g_resume.empty() || g_stop_at > 0)) {
+        std::cerr << "--checkpoint / --resume / --stop-at need # of GPUs = 1\n";
+        return 1;
+    }
     g_shards = numGPUs;
     std::cerr << "Rendering a " << width << "x" << height << " image with " << numGPUs << (numGPUs > 1 ? " GPUs" : " GPU");
     time_t now = time(0);
@@ -179,6 +267,10 @@ int main(int argc, char** argv)
         if (shards[g].scene) rt_scene_destroy(shards[g].scene);
     }
     const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (g_stop_at > 0 && g_stop_at < numSamples) {
+        std::cerr << "\nStopped after sample " << g_stop_at << " of " << numSamples << " in " << elapsed << " seconds" << std::endl;
+        return 0;
+    }
     const std::string stem = numGPUs > 1 ? "output/multiGPUTesting" : "output/singleGPUTesting";
     const std::string fileName = stem + ".png";
     std::cerr << "\nRendered in " << elapsed << " seconds to " << fileName << std::endl;

@@ -69,3 +69,31 @@ def test_user_scene_and_bad_input(tmp_path):
     assert r.returncode == 1
     r = run_driver(tmp_path, "16\n16\n1\n1\n", "no_such_scene")
     assert r.returncode == 99 and "unknown built-in scene" in r.stderr         # main.cu:33-44 exit code
+
+
+@pytest.mark.gpu
+def test_checkpoint_and_resume(tmp_path):
+    """an interrupted, resumed run ends with bit for bit the image of the uninterrupted run with the same --chunk"""
+    stdin = "48\n32\n8\n1\n"
+    whole, parts = tmp_path / "whole", tmp_path / "parts"
+    whole.mkdir()
+    parts.mkdir()
+    r = run_driver(whole, stdin, "cornell_smoke", "--chunk", "2")
+    assert r.returncode == 0 and "samples 8 / 8" in r.stderr, r.stderr
+    r = run_driver(parts, stdin, "cornell_smoke", "--chunk", "2", "--checkpoint", "ck.bin", "--stop-at", "4")
+    assert r.returncode == 0 and "Stopped after sample 4 of 8" in r.stderr, r.stderr
+    assert not (parts / "output").exists()
+    assert (parts / "ck.bin").stat().st_size == 72 + 48 * 32 * 3 * 4
+    r = run_driver(parts, stdin, "cornell_smoke", "--chunk", "2", "--resume", "ck.bin", "--checkpoint", "ck.bin")
+    assert r.returncode == 0 and "resuming at sample 4" in r.stderr, r.stderr
+    a = read_ppm(whole / "output" / "singleGPUTesting.ppm")
+    b = read_ppm(parts / "output" / "singleGPUTesting.ppm")
+    assert np.array_equal(a, b) and a.max() > 0
+    # the final checkpoint holds all 8 samples; a checkpoint of another render is refused
+    assert np.frombuffer((parts / "ck.bin").read_bytes()[16:24], np.uint32).tolist() == [8, 8]
+    r = run_driver(parts, "48\n32\n16\n1\n", "cornell_smoke", "--resume", "ck.bin")
+    assert r.returncode == 1 and "another render" in r.stderr
+    r = run_driver(parts, stdin, "cornell", "--resume", "ck.bin")
+    assert r.returncode == 1 and "another render" in r.stderr
+    r = run_driver(parts, stdin, "--no-such-option")
+    assert r.returncode == 1
