@@ -126,7 +126,7 @@ __global__ __launch_bounds__(RT_BLOCK) void trace_primary_kernel(DScene S, int W
 }
 
 template <uint32_t F, int BG>
-__global__ __launch_bounds__(RT_BLOCK, rt_render_waves(F)) void render_kernel(DScene S, int W, int H, uint32_t s_begin, uint32_t s_end,
+__global__ __launch_bounds__(RT_BLOCK, rt_render_waves(F)) void render_kernel(DScene S, int W, int H, int4 win, uint32_t s_begin, uint32_t s_end,
                                                            uint32_t k0, uint32_t k1, int max_depth,
                                                            float* __restrict__ accum,
                                                            unsigned long long* __restrict__ counters)
@@ -134,9 +134,12 @@ __global__ __launch_bounds__(RT_BLOCK, rt_render_waves(F)) void render_kernel(DS
     extern __shared__ int stack_mem[];                 /* RT_BLOCK ints, then RT_F_BVH: stack_depth x RT_BLOCK */
     int* slots = stack_mem + (threadIdx.x & ~63u);     /* 64 ints per wave for the wave-wide ball draw */
     int* stack = stack_mem + RT_BLOCK + ((F & RT_F_BVH) ? threadIdx.x : 0);
+    /* the grid tiles the window win = (x0, y0, width, height) of the W x H frame; pixel coordinates and the
+     * pixel index (RNG address, accum row) are the frame's, so a window renders what the full frame would */
     int i, j;
-    tile_pixel(W, xcd_tile(blockIdx.x, gridDim.x), threadIdx.x, i, j);
-    const bool valid = i < W && j < H;
+    tile_pixel(win.z, xcd_tile(blockIdx.x, gridDim.x), threadIdx.x, i, j);
+    const bool valid = i < win.z && j < win.w;
+    i += win.x; j += win.y;
     const uint32_t pixel = (uint32_t)(j * W + i);
 
     V3 sum = mk(0.f, 0.f, 0.f);
@@ -489,10 +492,10 @@ static int wf_reserve(rt_ctx* c, size_t n_slots)
 }
 
 template <uint32_t V>
-static int wf_run(rt_ctx* c, int w, int h, uint32_t s0, uint32_t s1, uint32_t k0, uint32_t k1, int max_depth,
+static int wf_run(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t s1, uint32_t k0, uint32_t k1, int max_depth,
                   int background, float* accum)
 {
-    const uint32_t n_pixels = (uint32_t)w * (uint32_t)h;
+    const uint32_t n_pixels = (uint32_t)win.z * (uint32_t)win.w;
     /* about RT_WF_SLOTS paths in flight (each persistent lane should see many rays per launch, so that the
      * drain at the end of a launch, when the queue is empty and waves wait for their last rays, stays small): K sample streams per pixel, never more than there are samples */
     uint32_t streams = (RT_WF_SLOTS + n_pixels - 1) / n_pixels;
@@ -503,6 +506,7 @@ static int wf_run(rt_ctx* c, int w, int h, uint32_t s0, uint32_t s1, uint32_t k0
     if (rc) return rc;
     WfState& W = c->wf;
     W.n_slots = (uint32_t)n_slots; W.n_pixels = n_pixels; W.streams = streams;
+    W.win_x0 = (uint32_t)win.x; W.win_y0 = (uint32_t)win.y; W.win_w = (uint32_t)win.z; W.frame_w = (uint32_t)w;
     if (c->stack4 > WF_LDS_STACK + WF_OVF_STACK) { rt_set_error("wavefront integrator: BVH deeper than its traversal stack"); return RT_ERR_UNSUPPORTED; }
     const size_t lds = (size_t)(c->stack4 < WF_LDS_STACK ? c->stack4 : WF_LDS_STACK) * RT_BLOCK * sizeof(int);
     HIPCHK(hipMemsetAsync(W.count, 0, 4 * sizeof(uint32_t), c->stream));
@@ -550,27 +554,36 @@ extern "C" int rt_ctx_set_integrator(rt_ctx* c, int mode)
 extern "C" int rt_render_accumulate(rt_ctx* c, int w, int h, uint32_t s0, uint32_t s1, uint64_t seed, int max_depth,
                                     int background, float* accum)
 {
+    if (!frame_ok(w, h)) { rt_set_error("rt_render_accumulate: bad arguments"); return RT_ERR_ARG; }
+    return rt_render_accumulate_window(c, w, h, 0, 0, w, h, s0, s1, seed, max_depth, background, accum);
+}
+
+extern "C" int rt_render_accumulate_window(rt_ctx* c, int w, int h, int x0, int y0, int x1, int y1, uint32_t s0, uint32_t s1,
+                                           uint64_t seed, int max_depth, int background, float* accum)
+{
     int rc = need_scene(c, "rt_render_accumulate");
     if (rc) return rc;
-    if (!frame_ok(w, h) || !accum || s1 < s0 || max_depth < 0 || (background != RT_BG_BLACK && background != RT_BG_SKY)) {
+    if (!frame_ok(w, h) || !accum || s1 < s0 || max_depth < 0 || (background != RT_BG_BLACK && background != RT_BG_SKY) ||
+        x0 < 0 || y0 < 0 || x1 > w || y1 > h || x0 >= x1 || y0 >= y1) {
         rt_set_error("rt_render_accumulate: bad arguments");
         return RT_ERR_ARG;
     }
+    const int4 win = make_int4(x0, y0, x1 - x0, y1 - y0);
     if (s1 == s0) return RT_OK;
     HIPCHK(hipSetDevice(c->device));
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
-    dim3 grid(n_tiles(w, h));
+    dim3 grid(n_tiles(win.z, win.w));
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     HIPCHK(hipEventRecord(e0, c->stream));
     /* auto: the wavefront form pays off once traversal dominates (measured: 2.2x on the 1M-triangle scene,
      * 0.8x on the final scene with its 11k BVH items and media in the world list) */
     const bool wavefront = c->integrator == RT_INTEGRATOR_WAVEFRONT || (c->integrator == RT_INTEGRATOR_AUTO && c->n_bvh_items >= RT_WF_AUTO_ITEMS && c->stack4 <= WF_LDS_STACK + WF_OVF_STACK);
     if (wavefront) {
-        int wrc = (c->features & ~RT_V_BVH_TRI) == 0 ? wf_run<RT_V_BVH_TRI>(c, w, h, s0, s1, k0, k1, max_depth, background, accum)
-                  : (c->features & RT_F_NOISE)       ? wf_run<RT_V_NOISE>(c, w, h, s0, s1, k0, k1, max_depth, background, accum)
-                                                     : wf_run<RT_F_ALL>(c, w, h, s0, s1, k0, k1, max_depth, background, accum);
+        int wrc = (c->features & ~RT_V_BVH_TRI) == 0 ? wf_run<RT_V_BVH_TRI>(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum)
+                  : (c->features & RT_F_NOISE)       ? wf_run<RT_V_NOISE>(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum)
+                                                     : wf_run<RT_F_ALL>(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum);
         HIPCHK(hipEventRecord(e1, c->stream));
         int nrc = note_render(c, e0, e1);
         return wrc ? wrc : nrc;
@@ -580,7 +593,7 @@ extern "C" int rt_render_accumulate(rt_ctx* c, int w, int h, uint32_t s0, uint32
     static const uint32_t variants[] = {RT_V_PLANAR, RT_V_PLANAR_MEDIA, RT_V_LIST, RT_V_BVH_TRI, RT_F_ALL, RT_V_NOISE};
     uint32_t pick = RT_V_NOISE;
     for (uint32_t v : variants) if ((c->features & ~v) == 0) { pick = v; break; }
-#define RT_LAUNCH(V, G) render_kernel<V, G><<<grid, RT_BLOCK, lds, c->stream>>>(c->ds, w, h, s0, s1, k0, k1, max_depth, accum, c->d_counters)
+#define RT_LAUNCH(V, G) render_kernel<V, G><<<grid, RT_BLOCK, lds, c->stream>>>(c->ds, w, h, win, s0, s1, k0, k1, max_depth, accum, c->d_counters)
 #define RT_LAUNCH_BG(V) { if (background == RT_BG_BLACK) RT_LAUNCH(V, RT_BG_BLACK); else RT_LAUNCH(V, RT_BG_SKY); }
     switch (pick) {
     case RT_V_PLANAR:       RT_LAUNCH_BG(RT_V_PLANAR) break;

@@ -35,8 +35,25 @@ struct WfState {
     float4* __restrict__ hit;     /* t, object, group, aux (bits) */
     uint32_t* __restrict__ queue[2];
     uint32_t* __restrict__ count; /* [0],[1] = entries of queue[0],queue[1]; [2] = intersect fetch head */
-    uint32_t n_slots, n_pixels, streams;
+    uint32_t n_slots, n_pixels, streams;    /* n_pixels = pixels of the rendered window */
+    uint32_t win_x0, win_y0, win_w, frame_w;   /* the window inside the frame (rt_render_accumulate_window) */
 };
+
+/* slot -> pixel: stream k of window pixel p is slot k * n_pixels + p; returns the pixel's index in the FRAME,
+ * which is what addresses the RNG and the accumulation buffer */
+__device__ __forceinline__ uint32_t wf_frame_pixel(const WfState& W, uint32_t slot, uint32_t& i, uint32_t& j)
+{
+    const uint32_t p = slot % W.n_pixels;
+    i = W.win_x0 + p % W.win_w;
+    j = W.win_y0 + p / W.win_w;
+    return j * W.frame_w + i;
+}
+__device__ __forceinline__ uint32_t wf_frame_pixel(const WfState& W, uint32_t slot)
+{
+    if (W.win_w == W.frame_w) return slot % W.n_pixels + W.win_y0 * W.frame_w;     /* full-width band: no division by the width */
+    uint32_t i, j;
+    return wf_frame_pixel(W, slot, i, j);
+}
 
 enum { WF_NEED = 0, WF_SCAN = 1, WF_BVH = 2 };
 #ifndef WF_INTERSECT_WAVES
@@ -118,7 +135,7 @@ __global__ __launch_bounds__(RT_BLOCK, WF_INTERSECT_WAVES) void wf_intersect_ker
                     rw.o = mk(o.x, o.y, o.z); rw.time = o.w;
                     rw.d = mk(d.x, d.y, d.z);
                     bounce = __float_as_uint(d.w);
-                    g.pixel = slot % W.n_pixels;
+                    g.pixel = wf_frame_pixel(W, slot);
                     g.sample = __float_as_uint(W.att[slot].w);
                     best.t = FLT_MAX; best.obj = -1; best.grp = -1; best.aux = 0;
                     rl = rw;
@@ -279,13 +296,13 @@ __global__ __launch_bounds__(RT_BLOCK, WF_INTERSECT_WAVES) void wf_intersect_ker
 }
 
 /* ---------------------------------------------------------------------- logic -- */
-/* slot -> pixel: stream k of pixel p is slot k * n_pixels + p */
 template <uint32_t F>
 __device__ __forceinline__ void wf_start_sample(const DScene& S, const WfState& W, uint32_t slot, uint32_t sample, int Wd, int Hd,
                                                 uint32_t k0, uint32_t k1, float4& o4, float4& d4, float4& a4, float4& e4)
 {
-    const uint32_t pixel = slot % W.n_pixels;
-    const int i = (int)(pixel % (uint32_t)Wd), j = (int)(pixel / (uint32_t)Wd);
+    uint32_t ui, uj;
+    const uint32_t pixel = wf_frame_pixel(W, slot, ui, uj);
+    const int i = (int)ui, j = (int)uj;
     PathRng g;
     rng_start(g, k0, k1, pixel, sample);
     rt_u32x4 cw = rng_block(g, RT_RNG_CAMERA, 0u, 0u);
@@ -363,7 +380,7 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_logic_kernel(DScene S, WfState W,
         att = mk(a.x, a.y, a.z); sample = __float_as_uint(a.w);
         emi = mk(em.x, em.y, em.z);
         hl.t = h.x; hl.obj = __float_as_int(h.y); hl.grp = __float_as_int(h.z); hl.aux = __float_as_int(h.w);
-        rng_start(g, k0, k1, slot % W.n_pixels, sample);
+        rng_start(g, k0, k1, wf_frame_pixel(W, slot), sample);
     }
     /* one iteration of colour() / colourUnlit(), main.cu:53-70 / :77-98 — same body as render_kernel */
     const bool hit = active && hl.obj >= 0;
@@ -440,7 +457,7 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_finalize_kernel(WfState W, float*
         const float4 s = W.sum[(size_t)k * W.n_pixels + p];
         x += s.x; y += s.y; z += s.z;
     }
-    float* a = accum + 3 * (size_t)p;
+    float* a = accum + 3 * (size_t)wf_frame_pixel(W, p);
     a[0] += x; a[1] += y; a[2] += z;
 }
 

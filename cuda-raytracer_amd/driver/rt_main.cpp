@@ -22,6 +22,8 @@
  * Optional argv: a built-in scene name (default "cornell" = the reference's active scene, main.cu:533;
  * "user" = the scene function in this file) and a scene parameter; and, with no counterpart in the reference
  * (progressive rendering):
+ *   --tiles            with N GPUs, split the IMAGE into N column bands (the reference's own split, main.cu:128-174,
+ *                      generalised from two halves) instead of splitting the samples; the reduce then acts as the stitch
  *   --chunk N          render N samples per call instead of all at once
  *   --checkpoint FILE  after every chunk write the sums so far (one GPU only); the file is replaced atomically
  *   --resume FILE      start from such a file; width, height, sample count and scene must be the same
@@ -81,6 +83,7 @@ static std::string g_scene = "cornell";
 static int g_param = 0;
 static int g_shards = 1;
 static int g_chunk = 0, g_stop_at = 0;
+static bool g_tiles = false;
 static std::string g_checkpoint, g_resume;
 
 /* checkpoint file: this header, then width*height*3 float sums (row 0 = bottom) */
@@ -161,6 +164,12 @@ static Shard renderShard(int width, int height, int numSamples, int gpuId)
     /* this shard's samples: [s0, s1) of the global range, so that N shards together render numSamples */
     uint32_t s0 = (uint32_t)((long long)numSamples * gpuId / g_shards);
     uint32_t s1 = (uint32_t)((long long)numSamples * (gpuId + 1) / g_shards);
+    int x0 = 0, x1 = width;
+    if (g_tiles) {                      /* every sample, this GPU's column band */
+        s0 = 0; s1 = (uint32_t)numSamples;
+        x0 = (int)((long long)width * gpuId / g_shards);
+        x1 = (int)((long long)width * (gpuId + 1) / g_shards);
+    }
     CheckpointHeader ck;
     std::memset(&ck, 0, sizeof ck);
     std::memcpy(ck.magic, "RTACCUM1", 8);
@@ -184,7 +193,7 @@ static Shard renderShard(int width, int height, int numSamples, int gpuId)
     const uint32_t chunk = g_chunk > 0 ? (uint32_t)g_chunk : (s1 > s0 ? s1 - s0 : 1u);
     for (uint32_t s = s0; s < s1; s += chunk) {
         const uint32_t e = s1 - s < chunk ? s1 : s + chunk;
-        checkRt(rt_render_accumulate(sh.ctx, width, height, s, e, /*seed*/419, /*depth*/100, background, sh.accum));
+        checkRt(rt_render_accumulate_window(sh.ctx, width, height, x0, 0, x1, height, s, e, /*seed*/419, /*depth*/100, background, sh.accum));
         checkRt(rt_synchronize(sh.ctx));
         if (!g_checkpoint.empty()) {
             host.resize(n);
@@ -196,7 +205,7 @@ static Shard renderShard(int width, int height, int numSamples, int gpuId)
     }
     rt_counters c;
     checkRt(rt_get_counters(sh.ctx, &c));
-    std::cerr << "GPU " << gpuId << ": samples [" << s0 << "," << s1 << "), " << c.rays << " rays in " << c.render_ms << " ms = "
+    std::cerr << "GPU " << gpuId << ": columns [" << x0 << "," << x1 << "), samples [" << s0 << "," << s1 << "), " << c.rays << " rays in " << c.render_ms << " ms = "
               << (c.render_ms > 0 ? c.rays / c.render_ms / 1e3 : 0.0) << " Mrays/s\n";
     return sh;
 }
@@ -207,7 +216,8 @@ int main(int argc, char** argv)
     for (int a = 1; a < argc; ++a) {
         const std::string arg = argv[a];
         const bool has_value = a + 1 < argc;
-        if (arg == "--chunk" && has_value) g_chunk = std::atoi(argv[++a]);
+        if (arg == "--tiles") g_tiles = true;
+        else if (arg == "--chunk" && has_value) g_chunk = std::atoi(argv[++a]);
         else if (arg == "--stop-at" && has_value) g_stop_at = std::atoi(argv[++a]);
         else if (arg == "--checkpoint" && has_value) g_checkpoint = argv[++a];
         else if (arg == "--resume" && has_value) g_resume = argv[++a];
@@ -234,7 +244,7 @@ int main(int argc, char** argv)
     checkHip(hipGetDeviceCount(&visible));
     if (numGPUs < 1) numGPUs = 1;
     if (numGPUs > visible) { std::cerr << "only " << visible << " GPU(s) visible\n"; numGPUs = visible > 0 ? visible : 1; }
-    if (numGPUs > numSamples) numGPUs = numSamples;
+    if (numGPUs > (g_tiles ? width : numSamples)) numGPUs = g_tiles ? width : numSamples;
     if (numGPUs > 1 && (!g_checkpoint.empty() || !g_resume.empty() || g_stop_at > 0)) {
         std::cerr << "--checkpoint / --resume / --stop-at need # of GPUs = 1\n";
         return 1;

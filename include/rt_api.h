@@ -101,6 +101,14 @@ int  rt_trace_primary(rt_ctx* c, int width, int height, float s_off, float t_off
  * context's stream. */
 int  rt_render_accumulate(rt_ctx* c, int width, int height, uint32_t sample_begin, uint32_t sample_end,
                           uint64_t seed, int max_depth, int background, float* accum_dev);
+/* The same for the pixels of the window [x0,x1) x [y0,y1) only; accum_dev is still the full W*H*3 buffer and
+ * pixels outside the window are not touched.  Image tiles are the other way to split a frame over GPUs: the
+ * reference's own two-GPU mode renders the left and right column halves (main.cu:128-174, gpuId 0/1) and
+ * stitches them on the host (main.cu:711-730).  A pixel's paths are addressed by (seed, frame pixel, sample),
+ * so windows that tile the frame add up to the full-frame image. */
+int  rt_render_accumulate_window(rt_ctx* c, int width, int height, int x0, int y0, int x1, int y1,
+                                 uint32_t sample_begin, uint32_t sample_end, uint64_t seed, int max_depth,
+                                 int background, float* accum_dev);
 /* Which form of the integrator rt_render_accumulate runs (no counterpart in the reference, whose render
  * kernel is one monolithic per-pixel loop, main.cu:125-198):
  *   RT_INTEGRATOR_MEGAKERNEL  one kernel, a path stays in its lane from camera to termination and the lane

@@ -97,3 +97,9 @@ def test_checkpoint_and_resume(tmp_path):
     assert r.returncode == 1 and "another render" in r.stderr
     r = run_driver(parts, stdin, "--no-such-option")
     assert r.returncode == 1
+    # image tiles instead of sample shards: with one GPU the one band is the whole frame
+    tiles = tmp_path / "tiles"
+    tiles.mkdir()
+    r = run_driver(tiles, stdin, "cornell_smoke", "--chunk", "2", "--tiles")
+    assert r.returncode == 0 and "columns [0,48)" in r.stderr, r.stderr
+    assert np.array_equal(read_ppm(tiles / "output" / "singleGPUTesting.ppm"), a)

@@ -371,3 +371,47 @@ def test_many_renders_between_counter_reads(binding, gpu_ctx):
     gpu_ctx.render_accumulate(acc, W, H, 0, 1, 419, 100, sc.background)      # ordered after the reset
     c = gpu_ctx.counters()
     assert c.render_launches == 1 and c.samples == W * H
+
+
+@pytest.mark.parametrize("integrator", INTEGRATORS)
+@pytest.mark.parametrize("name,param", [("cornell", 0), ("tri_mesh", 3000)])
+def test_windows_tile_the_frame(binding, gpu_ctx, name, param, integrator):
+    """image tiles (the reference's own 2-GPU split is column halves, main.cu:128-174): a window renders exactly the
+    paths the full frame renders for its pixels, touches nothing else, and windows that tile the frame add up to
+    the full-frame image; bad windows are refused"""
+    import torch
+    W, H, spp = 53, 37, 6
+    sc = binding.Scene(name, W, H, param)
+    gpu_ctx.upload(sc)
+    gpu_ctx.set_integrator({"megakernel": 1, "wavefront": 2}[integrator])
+    try:
+        full = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        gpu_ctx.render_accumulate(full, W, H, 2, 2 + spp, 419, 100, sc.background)
+        gpu_ctx.synchronize()
+        full = full.reshape(H, W, 3)
+        # left / right column halves as the reference splits them, then four uneven tiles
+        for windows in ([(0, 0, 27, H), (27, 0, W, H)], [(0, 0, 20, 17), (20, 0, W, 17), (0, 17, 33, H), (33, 17, W, H)]):
+            acc = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            gpu_ctx.reset_counters()
+            for k, win in enumerate(windows):
+                gpu_ctx.render_window(acc, W, H, win, 2, 2 + spp, 419, 100, sc.background)
+                gpu_ctx.synchronize()
+                img = acc.reshape(H, W, 3)
+                x0, y0, x1, y1 = win
+                mask = torch.zeros(H, W, dtype=torch.bool, device="cuda")
+                for (a0, b0, a1, b1) in windows[:k + 1]:
+                    mask[b0:b1, a0:a1] = True
+                assert float(img[~mask].abs().sum()) == 0.0, "a window wrote outside itself"
+                if integrator == "megakernel":
+                    assert torch.equal(img[y0:y1, x0:x1], full[y0:y1, x0:x1])
+            assert gpu_ctx.counters().samples == W * H * spp
+            # the wavefront form groups a pixel's samples into streams by the window's size: same paths, other rounding
+            assert torch.allclose(acc.reshape(H, W, 3), full, rtol=2e-5, atol=1e-5)
+        acc = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
+        for bad in [(-1, 0, 4, 4), (0, 0, W + 1, H), (5, 5, 5, 9), (9, 3, 4, 8), (0, H, 4, H + 1)]:
+            with pytest.raises(binding.RtError):
+                gpu_ctx.render_window(acc, W, H, bad, 0, 1, 419, 100, sc.background)
+    finally:
+        gpu_ctx.set_integrator(0)
