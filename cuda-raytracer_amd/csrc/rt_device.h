@@ -209,6 +209,55 @@ __device__ __forceinline__ bool box_t(const float* f, const DRay& r, float t0, f
     return any;
 }
 
+/* The two boundary queries of ConstantMedium::hit (Volumes.cuh:29-30) against a Box boundary, in one pass over
+ * the faces: boundary->hit(r, -FLT_MAX, FLT_MAX) then boundary->hit(r, t1 + .0001f, FLT_MAX).  A face's t and its
+ * bounds test do not depend on the query's range, so both queries run the reference's accept sequence (list order,
+ * shrinking closest-so-far, the same comparisons) over one set of six divisions.  Returns the number of queries
+ * that hit (0, 1, 2). */
+__device__ __forceinline__ int box_two_t(const float* f, const DRay& r, float& t1_out, float& t2_out)
+{
+    float t[6];
+    bool oob[6];
+#define RT_FACE_T(N, KA, A0, A1, B0, B1, K)                                             \
+    {                                                                                   \
+        const float ok_ = KA == 2 ? r.o.z : (KA == 1 ? r.o.y : r.o.x);                  \
+        const float dk_ = KA == 2 ? r.d.z : (KA == 1 ? r.d.y : r.d.x);                  \
+        const float oa_ = KA == 0 ? r.o.y : r.o.x, da_ = KA == 0 ? r.d.y : r.d.x;       \
+        const float ob_ = KA == 2 ? r.o.y : r.o.z, db_ = KA == 2 ? r.d.y : r.d.z;       \
+        t[N] = (K - ok_) / dk_;                                                         \
+        const float a_ = oa_ + t[N] * da_, b_ = ob_ + t[N] * db_;                       \
+        oob[N] = (a_ < A0) | (a_ > A1) | (b_ < B0) | (b_ > B1);                         \
+    }
+    RT_FACE_T(0, 2, f[0], f[3], f[1], f[4], f[5])
+    RT_FACE_T(1, 2, f[0], f[3], f[1], f[4], f[2])
+    RT_FACE_T(2, 1, f[0], f[3], f[2], f[5], f[4])
+    RT_FACE_T(3, 1, f[0], f[3], f[2], f[5], f[1])
+    RT_FACE_T(4, 0, f[1], f[4], f[2], f[5], f[3])
+    RT_FACE_T(5, 0, f[1], f[4], f[2], f[5], f[0])
+#undef RT_FACE_T
+    bool any = false;
+    float closest = FLT_MAX;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const bool h = !((t[k] < -FLT_MAX) | (t[k] > closest) | oob[k]);
+        any |= h;
+        closest = h ? t[k] : closest;
+    }
+    if (!any) return 0;
+    t1_out = closest;
+    const float t0 = closest + .0001f;
+    any = false;
+    closest = FLT_MAX;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const bool h = !((t[k] < t0) | (t[k] > closest) | oob[k]);
+        any |= h;
+        closest = h ? t[k] : closest;
+    }
+    t2_out = closest;
+    return any ? 2 : 1;
+}
+
 /* Triangle::hit Triangle.cuh:21-46 with the unit normal and plane offset precomputed on the
  * host by the same expressions (f[9..12]); plus the tMin<t<tMax filter */
 __device__ __forceinline__ bool triangle_t(const float* f, const DRay& r, float tMin, float tMax, float& t_out)
@@ -280,8 +329,14 @@ __device__ __forceinline__ bool medium_t(const DScene& S, const DObj& o, const D
     const DObj& b = S.objs[o.child_begin];
     float t1, t2;
     int unused;
-    if (!leaf_t<F>(S, b, r, -FLT_MAX, FLT_MAX, t1, unused)) return false;
-    if (!leaf_t<F>(S, b, r, t1 + .0001f, FLT_MAX, t2, unused)) return false;
+    if ((F & RT_F_PLANAR) && obj_type(b.head) == RT_OBJ_BOX) {
+        DRay rb = r;
+        if (F & RT_F_XFORM) apply_chain(S, b, rb);
+        if (box_two_t(b.f, rb, t1, t2) < 2) return false;
+    } else {
+        if (!leaf_t<F>(S, b, r, -FLT_MAX, FLT_MAX, t1, unused)) return false;
+        if (!leaf_t<F>(S, b, r, t1 + .0001f, FLT_MAX, t2, unused)) return false;
+    }
     if (t1 < tMin) t1 = tMin;
     if (t2 > tMax) t2 = tMax;
     if (t1 >= t2) return false;
