@@ -54,7 +54,9 @@ W, H = 128, 72
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--images", action="store_true")
+    ap.add_argument("--images", nargs="*", default=None, metavar="SCENE",
+                    help="also the slow converged renders (all of them, or only the scenes named)")
+    ap.add_argument("--images-only", action="store_true", help="leave the vector fixtures as they are")
     args = ap.parse_args()
     b = entry.load_binding()
     o = entry.load_oracle()
@@ -62,6 +64,9 @@ def main():
     scene_digest = o.scene_digest
     ref, orc = o.Reference(), o.Oracle()
     os.makedirs(GOLD, exist_ok=True)
+    if args.images_only:
+        make_images(args, b, orc)
+        return
     rng = np.random.default_rng(20261110)
 
     # ---- 1. per-object and whole-world closest hits -------------------------------------------
@@ -161,12 +166,18 @@ def main():
                         angles=angles, sincos=sc_, fuzz_in=fz, fuzz_out=np.array([ref.metal_fuzz(float(x)) for x in fz], np.float32))
     print("misc ok")
 
+    make_images(args, b, orc)
+
+
+def make_images(args, b, orc):
     # ---- 4. converged images from the restatement (slow) ------------------------------------------
-    if args.images:
+    if args.images is not None:
         IW = IH = 48
         for name, spp, bvh in [("cornell", 262144, False), ("cornell_smoke", 262144, False),
-                               ("random_spheres", 16384, True), ("lit_sphere", 65536, False)]:
-            sc = b.Scene(name, IW, IH)
+                               ("random_spheres", 16384, True), ("lit_sphere", 65536, False), ("final", 65536, True)]:
+            if args.images and name not in args.images:
+                continue
+            sc = b.Scene(name, IW, IH, 8 if name == "final" else 0)      # final: the mini scene, 8 x 8 boxes
             acc, st = orc.render(sc.flat, IW, IH, 0, spp, 1000003, 100, sc.background, use_bvh=bvh, threads=os.cpu_count() or 1)
             img = (acc / np.float32(spp)).astype(np.float32)
             np.savez_compressed(os.path.join(GOLD, "image_%s_oracle.npz" % name), digest=scene_digest(sc.flat), image=img,

@@ -189,7 +189,7 @@ def test_virtual_shards_reduce_to_the_single_gpu_image(binding, gpu_ctx):
         assert torch.allclose(tot, full, rtol=1e-5, atol=1e-6), world
 
 
-@pytest.mark.parametrize("name", ["cornell", "cornell_smoke", "random_spheres", "lit_sphere"])
+@pytest.mark.parametrize("name", ["cornell", "cornell_smoke", "random_spheres", "lit_sphere", "final"])
 def test_converged_image_rmse(binding, oracle_mod, gpu_ctx, name):
     """north_star criterion 2: linear RMSE <= 1e-3 against the oracle's converged image (different seed)"""
     import os
@@ -199,7 +199,7 @@ def test_converged_image_rmse(binding, oracle_mod, gpu_ctx, name):
         pytest.skip("no converged golden for " + name)
     g = np.load(path)
     W, H = int(g["width"]), int(g["height"])
-    sc = binding.Scene(name, W, H)
+    sc = binding.Scene(name, W, H, 8 if name == "final" else 0)      # final: the mini scene of the golden
     assert oracle_mod.scene_digest(sc.flat) == str(g["digest"])
     gpu_ctx.upload(sc)
     spp = 4 * int(g["spp"])
