@@ -503,19 +503,10 @@ __device__ __forceinline__ ProgRec prog_load(const DProg* p)
  * as the scan program of rt_host.h: every lane of the wave executes the same record, so records come
  * through the scalar cache and the next one is requested before the current one is evaluated. */
 template <uint32_t F>
-__device__ __forceinline__ HitLite closest_hit(const DScene& S, const DRay& r, float tMin, float tMax,
-                                               const PathRng* rng, uint32_t bounce, int* stack)
+__device__ __forceinline__ void scan_program(const DScene& S, const DProg* pc, const DRay& r, float tMin, HitLite& best,
+                                             const PathRng* rng, uint32_t bounce, int* stack)
 {
-    HitLite best = {tMax, -1, -1, 0};
-    if (F & RT_F_BVH) {
-        const DObj& w = S.objs[S.world];
-        if (obj_flags(w.head) & RT_DOBJ_HAS_BVH) {
-            group_closest<F>(S, -1, w, r, tMin, best, rng, bounce, stack);
-            return best;
-        }
-    }
     DRay rl = r;                                   /* the ray in the current record's frame */
-    const DProg* pc = S.prog;
     ProgRec cur = prog_load(pc);
     while (true) {
         const int kind = (int)(cur.head & 0xffu);
@@ -567,6 +558,20 @@ __device__ __forceinline__ HitLite closest_hit(const DScene& S, const DRay& r, f
         }
         cur = nxt;
     }
+}
+template <uint32_t F>
+__device__ __forceinline__ HitLite closest_hit(const DScene& S, const DRay& r, float tMin, float tMax,
+                                               const PathRng* rng, uint32_t bounce, int* stack)
+{
+    HitLite best = {tMax, -1, -1, 0};
+    if (F & RT_F_BVH) {
+        const DObj& w = S.objs[S.world];
+        if (obj_flags(w.head) & RT_DOBJ_HAS_BVH) {
+            group_closest<F>(S, -1, w, r, tMin, best, rng, bounce, stack);
+            return best;
+        }
+    }
+    scan_program<F>(S, S.prog, r, tMin, best, rng, bounce, stack);
     return best;
 }
 

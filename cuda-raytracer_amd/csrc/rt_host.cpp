@@ -251,9 +251,17 @@ void rt_pack_bvh4(const rt_flat_scene* s, std::vector<DObj>& objs, std::vector<D
     if (depth) *depth = deepest;
 }
 
-void rt_pack_program(const rt_flat_scene* s, std::vector<DProg>& prog)
+void rt_pack_program(const rt_flat_scene* s, std::vector<DProg>& prog, std::vector<DProg>* prog_nobvh, std::vector<int>* bvh_groups)
 {
     prog.clear();
+    if (prog_nobvh) prog_nobvh->clear();
+    if (bvh_groups) bvh_groups->clear();
+    /* both programs get every record except that BVH groups go to the group list instead of prog_nobvh */
+    auto emit = [&](const DProg& r, bool bvh_group) {
+        prog.push_back(r);
+        if (bvh_group) { if (bvh_groups) bvh_groups->push_back(r.obj); }
+        else if (prog_nobvh) prog_nobvh->push_back(r);
+    };
     const rt_object& w = s->objects[s->world];
     /* the wrapper chain the scan's local ray currently has: starts as the world frame */
     int cur_n = 0;
@@ -266,6 +274,7 @@ void rt_pack_program(const rt_flat_scene* s, std::vector<DProg>& prog)
         return true;
     };
     /* a world that has a BVH of its own is traversed directly: no scan records */
+    if (w.bvh_root >= 0 && bvh_groups) bvh_groups->push_back(s->world);
     for (int i = 0; i < (w.bvh_root >= 0 ? 0 : w.child_count); ++i) {
         const int oi = w.child_begin + i;
         const rt_object& o = s->objects[oi];
@@ -275,7 +284,7 @@ void rt_pack_program(const rt_flat_scene* s, std::vector<DProg>& prog)
         const bool simple = (o.type == RT_OBJ_SPHERE || (o.type >= RT_OBJ_RECT_XY && o.type <= RT_OBJ_BOX)) && o.op_count <= 2;
         /* a GENERIC record may leave the scan's local ray in its own frame (a BVH group is traversed in
          * place by the wavefront intersect kernel): the next simple object re-establishes its frame */
-        if (!simple) { r.head = RT_P_GENERIC; prog.push_back(r); cur_n = -1; continue; }
+        if (!simple) { r.head = RT_P_GENERIC; emit(r, o.type == RT_OBJ_GROUP && o.bvh_root >= 0); cur_n = -1; continue; }
         if (!same_chain(o)) {
             DProg x;
             std::memset(&x, 0, sizeof x);
@@ -288,30 +297,30 @@ void rt_pack_program(const rt_flat_scene* s, std::vector<DProg>& prog)
                 x.v[3 * k] = cur[k].a; x.v[3 * k + 1] = cur[k].b; x.v[3 * k + 2] = cur[k].c;
             }
             x.head = RT_P_XFORM | ((uint32_t)cur_n << 8) | (ty[0] << 16) | (ty[1] << 20);
-            prog.push_back(x);
+            emit(x, false);
         }
         const float* f = o.f;
         if (o.type == RT_OBJ_SPHERE) {
             r.head = RT_P_SPHERE;
             for (int k = 0; k < 4; ++k) r.v[k] = f[k];
-            prog.push_back(r);
+            emit(r, false);
         } else if (o.type == RT_OBJ_BOX) {
             /* one record, six faces tested in the order of Box.cuh:24-36 by straight-line code */
             r.head = RT_P_BOX;
             for (int k = 0; k < 6; ++k) r.v[k] = f[k];
-            prog.push_back(r);
+            emit(r, false);
         } else {
             const int ka = RT_OBJ_RECT_YZ - o.type;   /* XY -> 2, XZ -> 1, YZ -> 0 */
             r.head = RT_P_RECT | ((uint32_t)ka << 8);
             r.v[0] = f[4]; r.v[1] = f[0]; r.v[2] = f[1]; r.v[3] = f[2]; r.v[4] = f[3];
-            prog.push_back(r);
+            emit(r, false);
         }
     }
     DProg e;
     std::memset(&e, 0, sizeof e);
     e.head = RT_P_END;
-    prog.push_back(e);
-    prog.push_back(e);   /* the scan prefetches one record past the one it runs */
+    emit(e, false);
+    emit(e, false);      /* the scan prefetches one record past the one it runs */
 }
 
 uint32_t rt_scene_features(const rt_flat_scene* s)

@@ -107,7 +107,12 @@ bool rt_pack_bvh(const rt_flat_scene* s, std::vector<DObj>& objs, std::vector<DN
 void rt_pack_bvh4(const rt_flat_scene* s, std::vector<DObj>& objs, std::vector<DNode4>& nodes4, int* depth);
 
 /* the world list -> program records (terminated by one RT_P_END record) */
-void rt_pack_program(const rt_flat_scene* s, std::vector<DProg>& prog);
+/* prog: the world list as scan records.  For the wavefront integrator, which runs the list's plain records when
+ * it hands a ray to a lane and then walks the BVH groups one after the other: prog_nobvh = the same program
+ * without the records of BVH groups, bvh_groups = those groups' object indices in list order (the world
+ * itself when it has a BVH of its own). */
+void rt_pack_program(const rt_flat_scene* s, std::vector<DProg>& prog, std::vector<DProg>* prog_nobvh = nullptr,
+                     std::vector<int>* bvh_groups = nullptr);
 
 /* RT_F_* bits the scene uses */
 uint32_t rt_scene_features(const rt_flat_scene* s);

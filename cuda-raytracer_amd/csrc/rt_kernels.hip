@@ -286,6 +286,8 @@ struct rt_ctx {
     DScene ds;
     void* d_objs = nullptr;  void* d_ops = nullptr;   void* d_mats = nullptr; void* d_texs = nullptr;
     void* d_image = nullptr; void* d_nodes = nullptr; void* d_leafs = nullptr; void* d_prog = nullptr; void* d_nodes4 = nullptr;
+    void* d_prog_wf = nullptr; void* d_wf_groups = nullptr;   /* the world list in the wavefront integrator's form */
+    int n_wf_groups = 0;
     unsigned long long* d_counters = nullptr;
     /* render launches whose event pair has not been read back yet are timed lazily */
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -295,7 +297,8 @@ struct rt_ctx {
 
 static void free_scene(rt_ctx* c)
 {
-    void** ptrs[] = {&c->d_objs, &c->d_ops, &c->d_mats, &c->d_texs, &c->d_image, &c->d_nodes, &c->d_leafs, &c->d_prog, &c->d_nodes4};
+    void** ptrs[] = {&c->d_objs, &c->d_ops, &c->d_mats, &c->d_texs, &c->d_image, &c->d_nodes, &c->d_leafs, &c->d_prog, &c->d_nodes4,
+                     &c->d_prog_wf, &c->d_wf_groups};
     for (void** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
     c->have_scene = false;
 }
@@ -362,8 +365,9 @@ extern "C" int rt_scene_upload(rt_ctx* c, const rt_flat_scene* s)
     std::vector<DNode4> nodes4;
     int depth4 = 0;
     rt_pack_bvh4(s, objs, nodes4, &depth4);
-    std::vector<DProg> prog;
-    rt_pack_program(s, prog);
+    std::vector<DProg> prog, prog_wf;
+    std::vector<int> wf_groups;
+    rt_pack_program(s, prog, &prog_wf, &wf_groups);
     if (stack_depth > RT_MAX_STACK) { rt_set_error("rt_scene_upload: BVH deeper than the traversal stack (64)"); return RT_ERR_UNSUPPORTED; }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -394,7 +398,10 @@ extern "C" int rt_scene_upload(rt_ctx* c, const rt_flat_scene* s)
     if ((rc = upload(c, &c->d_leafs, leafs.data(), leafs.size()))) return rc;
     if ((rc = upload(c, &c->d_prog, prog.data(), prog.size()))) return rc;
     if ((rc = upload(c, &c->d_nodes4, nodes4.data(), nodes4.size()))) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream)); /* objs, nodes, nodes4, leafs, prog and mats are locals */
+    if ((rc = upload(c, &c->d_prog_wf, prog_wf.data(), prog_wf.size()))) return rc;
+    if ((rc = upload(c, &c->d_wf_groups, wf_groups.data(), wf_groups.size()))) return rc;
+    c->n_wf_groups = (int)wf_groups.size();
+    HIPCHK(hipStreamSynchronize(c->stream)); /* objs, nodes, nodes4, leafs, the programs and mats are locals */
     c->ds.objs = (const DObj*)c->d_objs;
     c->ds.ops = (const rt_xform_op*)c->d_ops;
     c->ds.mats = (const rt_material*)c->d_mats;
@@ -507,6 +514,7 @@ static int wf_run(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t s1, u
     WfState& W = c->wf;
     W.n_slots = (uint32_t)n_slots; W.n_pixels = n_pixels; W.streams = streams;
     W.win_x0 = (uint32_t)win.x; W.win_y0 = (uint32_t)win.y; W.win_w = (uint32_t)win.z; W.frame_w = (uint32_t)w;
+    W.prog = (const DProg*)c->d_prog_wf; W.groups = (const int*)c->d_wf_groups; W.n_groups = c->n_wf_groups;
     if (c->stack4 > WF_LDS_STACK + WF_OVF_STACK) { rt_set_error("wavefront integrator: BVH deeper than its traversal stack"); return RT_ERR_UNSUPPORTED; }
     const size_t lds = (size_t)(c->stack4 < WF_LDS_STACK ? c->stack4 : WF_LDS_STACK) * RT_BLOCK * sizeof(int);
     HIPCHK(hipMemsetAsync(W.count, 0, 4 * sizeof(uint32_t), c->stream));

@@ -37,6 +37,11 @@ struct WfState {
     uint32_t* __restrict__ count; /* [0],[1] = entries of queue[0],queue[1]; [2] = intersect fetch head */
     uint32_t n_slots, n_pixels, streams;    /* n_pixels = pixels of the rendered window */
     uint32_t win_x0, win_y0, win_w, frame_w;   /* the window inside the frame (rt_render_accumulate_window) */
+    /* the world list for this integrator (rt_host.h rt_pack_program): its plain records, run in one go when a ray
+     * is handed to a lane, and the BVH groups, walked one after the other by the step loop */
+    const DProg* __restrict__ prog;
+    const int* __restrict__ groups;
+    int n_groups;
 };
 
 /* slot -> pixel: stream k of window pixel p is slot k * n_pixels + p; returns the pixel's index in the FRAME,
@@ -55,7 +60,7 @@ __device__ __forceinline__ uint32_t wf_frame_pixel(const WfState& W, uint32_t sl
     return wf_frame_pixel(W, slot, i, j);
 }
 
-enum { WF_NEED = 0, WF_SCAN = 1, WF_BVH = 2 };
+enum { WF_NEED = 0, WF_BVH = 2 };
 #ifndef WF_INTERSECT_WAVES
 #define WF_INTERSECT_WAVES 4   /* waves per SIMD the intersect kernel is compiled for */
 #endif
@@ -79,19 +84,32 @@ __global__ __launch_bounds__(RT_BLOCK, WF_INTERSECT_WAVES) void wf_intersect_ker
     const uint32_t* __restrict__ queue = W.queue[qi];
     const int lane = (int)(threadIdx.x & 63u);
     const float tMin = .001f;
-    const uint32_t whead = S.objs[S.world].head;
-    const bool world_bvh = (obj_flags(whead) & RT_DOBJ_HAS_BVH) != 0;
-    const int world_root = S.objs[S.world].pad[0];       /* root of the 4-wide tree */
 
     int mode = WF_NEED;
     uint32_t slot = 0;
     DRay rw = {mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f), 0.f}, rl = rw;
     V3 id = mk(0.f, 0.f, 0.f);
     HitLite best = {FLT_MAX, -1, -1, 0};
-    int pc = 0, gi = -1, ref = RT_REF_NONE, pleaf = RT_REF_NONE, sp = 0, li = 0;
+    int gidx = 0, gi = -1, ref = RT_REF_NONE, pleaf = RT_REF_NONE, sp = 0, li = 0;
     int ovf[WF_OVF_STACK];                      /* stack entries beyond WF_LDS_STACK (scratch) */
 #define WF_PUSH(v) { const int v_ = (v); if (sp < WF_LDS_STACK) stack[sp * RT_BLOCK] = v_; else ovf[sp - WF_LDS_STACK] = v_; ++sp; }
 #define WF_POP(dst) { dst = RT_REF_NONE; if (sp > 0) { --sp; dst = sp < WF_LDS_STACK ? stack[sp * RT_BLOCK] : ovf[sp - WF_LDS_STACK]; } }
+    /* the ray enters the gidx-th BVH group of the world list (GENERIC record of closest_hit: the group's own
+     * wrapper chain on the world ray), or, past the last group, is finished: its hit goes to HBM */
+#define WF_NEXT_GROUP                                                                                            \
+    {                                                                                                            \
+        if (gidx < W.n_groups) {                                                                                 \
+            const int obj_ = W.groups[gidx];                                                                     \
+            const DObj& o_ = S.objs[obj_];                                                                       \
+            rl = rw;                                                                                             \
+            if (F & RT_F_XFORM) apply_chain(S, o_, rl);                                                          \
+            id = mk(1.f / rl.d.x, 1.f / rl.d.y, 1.f / rl.d.z);                                                   \
+            mode = WF_BVH; gi = obj_ == S.world ? -1 : obj_; ref = o_.pad[0]; pleaf = RT_REF_NONE; sp = 0; li = 0; \
+        } else {                                                                                                 \
+            W.hit[slot] = make_float4(best.t, __int_as_float(best.obj), __int_as_float(best.grp), __int_as_float(best.aux)); \
+            mode = WF_NEED;                                                                                      \
+        }                                                                                                        \
+    }
     PathRng g;
     rng_start(g, k0, k1, 0u, 0u);
     uint32_t bounce = 0;
@@ -103,7 +121,7 @@ __global__ __launch_bounds__(RT_BLOCK, WF_INTERSECT_WAVES) void wf_intersect_ker
     uint32_t chunk = n_queue / (gridDim.x * (RT_BLOCK / 64) * 2u);
     chunk = chunk < 16u ? 16u : (chunk > (uint32_t)WF_CHUNK ? (uint32_t)WF_CHUNK : chunk);
 #ifdef RT_STAMPS
-    unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* trips, busy lanes, node, prim, scan lanes, trips with scan, with prim, cycles */
+    unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* trips, busy lanes, node, prim, -, -, with prim, cycles */
     const unsigned long long dg_t0 = __builtin_amdgcn_s_memtime();
 #endif
 
@@ -138,58 +156,48 @@ __global__ __launch_bounds__(RT_BLOCK, WF_INTERSECT_WAVES) void wf_intersect_ker
                     g.pixel = wf_frame_pixel(W, slot);
                     g.sample = __float_as_uint(W.att[slot].w);
                     best.t = FLT_MAX; best.obj = -1; best.grp = -1; best.aux = 0;
-                    rl = rw;
-                    sp = 0; li = 0; pleaf = RT_REF_NONE;
                     ++n_rays;
-                    if ((F & RT_F_BVH) && world_bvh) {
-                        mode = WF_BVH; gi = -1; ref = world_root; pc = -1;
-                        id = mk(1.f / rl.d.x, 1.f / rl.d.y, 1.f / rl.d.z);
-                    } else {
-                        mode = WF_SCAN; pc = 0;
-                    }
+                    /* the plain records of the world list, for all the lanes of this batch together (one scalar
+                     * record stream, as in the megakernel's closest_hit), then on to the first BVH group */
+                    scan_program<(F & ~RT_F_BVH)>(S, W.prog, rw, tMin, best, &g, bounce, stack);
+                    gidx = 0;
+                    WF_NEXT_GROUP
                 }
             }
         }
         if (__ballot(mode != WF_NEED) == 0ull) {
             if (drained) break;
-            continue;                            /* fewer than 16 idle lanes cannot happen here: all 64 are idle */
+            continue;                            /* a batch that finished at once (no BVH group), or all 64 lanes idle */
         }
 
         /* ---- one trip ----
-         * The kinds of step cost very differently (a 4-wide node ~130 VALU instructions, a triangle ~130, a
-         * scan record 50-100) and a trip pays for every kind any lane runs, so each kind should run with as
-         * many lanes as possible:
+         * The kinds of step cost very differently (a 4-wide node ~130 VALU instructions, a triangle ~130) and
+         * a trip pays for every kind any lane runs, so each kind should run with as many lanes as possible:
          *  - a lane that reaches a leaf does not stop to test it: the leaf is POSTPONED (`pleaf`) and the
          *    lane goes on with the next node from its stack; it can take a node step and a primitive step in
          *    the same trip, and only stalls when a second leaf turns up before the first is finished;
-         *  - primitive steps run once WF_PRIM_BATCH lanes hold a postponed leaf, or the node steps run low;
-         *    scan records likewise.
+         *  - primitive steps run once WF_PRIM_BATCH lanes hold a postponed leaf, or the node steps run low.
          * The closest hit does not depend on the order in which a ray's leaves are tested (exact ties aside). */
         const bool in_bvh = mode == WF_BVH;
         const bool interior = in_bvh && ref >= 0;
         const bool has_leaf = in_bvh && pleaf != RT_REF_NONE;
-        const bool in_scan = mode == WF_SCAN;
-        const int n_node = __popcll(__ballot(interior)), n_prim = __popcll(__ballot(has_leaf)), n_scan = __popcll(__ballot(in_scan));
+        const int n_node = __popcll(__ballot(interior)), n_prim = __popcll(__ballot(has_leaf));
         const bool do_prim = n_prim >= WF_PRIM_BATCH || (n_prim > 0 && n_node < WF_NODE_LOW);
-        const bool do_scan = n_scan >= WF_SCAN_BATCH || (n_scan > 0 && n_node < WF_NODE_LOW && !do_prim) || (n_scan > 0 && n_node + n_prim == 0);
         const bool prim_step = has_leaf && do_prim;
-        const bool scan_step = in_scan && do_scan;
 #ifdef RT_STAMPS
         {
             const int nb = __popcll(__ballot(mode != WF_NEED));
-            dg[0] += 1; dg[1] += nb; dg[2] += n_node; dg[3] += do_prim ? n_prim : 0; dg[4] += do_scan ? n_scan : 0; dg[5] += do_scan ? 1 : 0; dg[6] += do_prim ? 1 : 0;
+            dg[0] += 1; dg[1] += nb; dg[2] += n_node; dg[3] += do_prim ? n_prim : 0; dg[6] += do_prim ? 1 : 0;
         }
 #endif
         /* the loads of both steps of the trip go out together */
         const int lfirst = (~pleaf) >> 4, lcount = ((~pleaf) & 15) + 1;
         const float4* nsrc = reinterpret_cast<const float4*>(S.nodes4 + (interior ? ref : 0));
-        const float4* src = prim_step ? reinterpret_cast<const float4*>(S.leafs + (lfirst + li))
-                                      : reinterpret_cast<const float4*>(S.prog + (scan_step ? pc : 0));
+        const float4* src = reinterpret_cast<const float4*>(S.leafs + (prim_step ? lfirst + li : 0));
         float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0, n3 = n0, n4 = n0, n5 = n0, n6 = n0;
         float4 q0 = n0, q1 = n0, q2 = n0, q3 = n0;
         if (interior) { n0 = nsrc[0]; n1 = nsrc[1]; n2 = nsrc[2]; n3 = nsrc[3]; n4 = nsrc[4]; n5 = nsrc[5]; n6 = nsrc[6]; }
-        if (prim_step || scan_step) { q0 = src[0]; q1 = src[1]; }
-        if (prim_step) { q2 = src[2]; q3 = src[3]; }
+        if (prim_step) { q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3]; }
 
         if (interior) {
             const float b0[6] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y}, b1[6] = {n1.z, n1.w, n2.x, n2.y, n2.z, n2.w};
@@ -226,66 +234,10 @@ __global__ __launch_bounds__(RT_BLOCK, WF_INTERSECT_WAVES) void wf_intersect_ker
         if (in_bvh) {
             /* a leaf reference in `ref` moves to the postponed slot as soon as that is free */
             if (pleaf == RT_REF_NONE && ref < 0 && ref != RT_REF_NONE) { pleaf = ref; li = 0; WF_POP(ref) }
-            if (ref == RT_REF_NONE && pleaf == RT_REF_NONE) { mode = WF_SCAN; ++pc; }   /* the group is done: on with the world list */
-        } else if (scan_step) {
-            const uint32_t head = __float_as_uint(q0.x);
-            const int kind = (int)(head & 0xffu);
-            const int obj = __float_as_int(q0.y);
-            if (kind == RT_P_END) {
-                W.hit[slot] = make_float4(best.t, __int_as_float(best.obj), __int_as_float(best.grp), __int_as_float(best.aux));
-                mode = WF_NEED;
-            } else if (kind == RT_P_RECT) {
-                if (F & RT_F_PLANAR) {
-                    const int ka = (int)((head >> 8) & 0xffu);
-                    /* run-time axis: pick the ray components, then the reference's arithmetic (Rectangle.cuh:24-38) */
-                    DRay ra;
-                    ra.o = mk(ka == 0 ? rl.o.y : rl.o.x, ka == 2 ? rl.o.y : rl.o.z, ka == 2 ? rl.o.z : (ka == 1 ? rl.o.y : rl.o.x));
-                    ra.d = mk(ka == 0 ? rl.d.y : rl.d.x, ka == 2 ? rl.d.y : rl.d.z, ka == 2 ? rl.d.z : (ka == 1 ? rl.d.y : rl.d.x));
-                    ra.time = rl.time;
-                    /* ra = (a, b, k) components; rect_t<2> reads a = x, b = y, k = z */
-                    float t;
-                    if (rect_t<2>(q0.w, q1.x, q1.y, q1.z, q0.z, ra, tMin, best.t, t)) {
-                        best.t = t; best.obj = obj; best.grp = -1; best.aux = (int)((head >> 16) & 0xffu);
-                    }
-                }
-                ++pc;
-            } else if (kind == RT_P_BOX) {
-                if (F & RT_F_PLANAR) {
-                    const float f[6] = {q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-                    float t; int face;
-                    if (box_t(f, rl, tMin, best.t, t, face)) { best.t = t; best.obj = obj; best.grp = -1; best.aux = face; }
-                }
-                ++pc;
-            } else if (kind == RT_P_XFORM) {
-                if (F & RT_F_XFORM) {
-                    rl = rw;
-                    const int n = (int)((head >> 8) & 0xffu);
-                    if (n > 0) apply_op((int)((head >> 16) & 0xfu), q0.z, q0.w, q1.x, rl);
-                    if (n > 1) apply_op((int)((head >> 20) & 0xfu), q1.y, q1.z, q1.w, rl);
-                }
-                ++pc;
-            } else if (kind == RT_P_SPHERE) {
-                if (F & RT_F_SPHERE) {
-                    float t;
-                    if (sphere_t(mk(q0.z, q0.w, q1.x), q1.y, rl, tMin, best.t, t)) { best.t = t; best.obj = obj; best.grp = -1; best.aux = 0; }
-                }
-                ++pc;
-            } else { /* RT_P_GENERIC */
-                const DObj& o = S.objs[obj];
-                const uint32_t oh = o.head;
-                if ((F & RT_F_BVH) && obj_type(oh) == RT_OBJ_GROUP && (obj_flags(oh) & RT_DOBJ_HAS_BVH)) {
-                    rl = rw;
-                    if (F & RT_F_XFORM) apply_chain(S, o, rl);
-                    id = mk(1.f / rl.d.x, 1.f / rl.d.y, 1.f / rl.d.z);
-                    mode = WF_BVH; gi = obj; ref = o.pad[0]; pleaf = RT_REF_NONE; sp = 0; li = 0;
-                    /* pc stays on this record; it advances when the traversal ends */
-                } else {
-                    generic_closest<F & ~RT_F_BVH>(S, obj, rw, tMin, best, &g, bounce, stack);
-                    ++pc;
-                }
-            }
+            if (ref == RT_REF_NONE && pleaf == RT_REF_NONE) { ++gidx; WF_NEXT_GROUP }   /* the group is done */
         }
     }
+#undef WF_NEXT_GROUP
     unsigned long long r = n_rays;
     for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off);
     if (lane == 0) atomicAdd(&counters[0], r);
