@@ -16,6 +16,7 @@
 #include <dlfcn.h>
 #include <mutex>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -33,7 +34,8 @@
 #define RT_V_BVH_TRI      (RT_F_BVH | RT_F_TRI | RT_F_PLANAR)                          /* triangle mesh + area light */
 #define RT_V_NOISE        (RT_F_ALL | RT_F_NOISE)                                      /* anything with a NoiseTexture */
 #ifndef RT_WF_AUTO_ITEMS
-#define RT_WF_AUTO_ITEMS 65536
+#define RT_WF_AUTO_ITEMS 65536        /* BVH items from which RT_INTEGRATOR_AUTO takes the wavefront form ... */
+#define RT_WF_AUTO_ITEMS_LIST 1000    /* ... or from this many when the world list also holds >= 4 plain records */
 #endif
 #ifndef RT_WF_SLOTS
 #define RT_WF_SLOTS (1u << 23)
@@ -287,7 +289,7 @@ struct rt_ctx {
     void* d_objs = nullptr;  void* d_ops = nullptr;   void* d_mats = nullptr; void* d_texs = nullptr;
     void* d_image = nullptr; void* d_nodes = nullptr; void* d_leafs = nullptr; void* d_prog = nullptr; void* d_nodes4 = nullptr;
     void* d_prog_wf = nullptr; void* d_wf_groups = nullptr;   /* the world list in the wavefront integrator's form */
-    int n_wf_groups = 0;
+    int n_wf_groups = 0, n_wf_plain = 0;
     unsigned long long* d_counters = nullptr;
     /* render launches whose event pair has not been read back yet are timed lazily */
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -401,6 +403,7 @@ extern "C" int rt_scene_upload(rt_ctx* c, const rt_flat_scene* s)
     if ((rc = upload(c, &c->d_prog_wf, prog_wf.data(), prog_wf.size()))) return rc;
     if ((rc = upload(c, &c->d_wf_groups, wf_groups.data(), wf_groups.size()))) return rc;
     c->n_wf_groups = (int)wf_groups.size();
+    c->n_wf_plain = (int)prog_wf.size() - 2;      /* without the two terminators */
     HIPCHK(hipStreamSynchronize(c->stream)); /* objs, nodes, nodes4, leafs, the programs and mats are locals */
     c->ds.objs = (const DObj*)c->d_objs;
     c->ds.ops = (const rt_xform_op*)c->d_ops;
@@ -515,6 +518,9 @@ static int wf_run(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t s1, u
     W.n_slots = (uint32_t)n_slots; W.n_pixels = n_pixels; W.streams = streams;
     W.win_x0 = (uint32_t)win.x; W.win_y0 = (uint32_t)win.y; W.win_w = (uint32_t)win.z; W.frame_w = (uint32_t)w;
     W.prog = (const DProg*)c->d_prog_wf; W.groups = (const int*)c->d_wf_groups; W.n_groups = c->n_wf_groups;
+    /* a refill runs the plain records of the world list for the lanes it fills: the longer that list, the more
+     * lanes it should wait for (measured: 1 record -> 32 best, the final scene's 11 -> 48) */
+    W.refill_min = c->n_wf_plain <= 4 ? 32 : 48;
     if (c->stack4 > WF_LDS_STACK + WF_OVF_STACK) { rt_set_error("wavefront integrator: BVH deeper than its traversal stack"); return RT_ERR_UNSUPPORTED; }
     const size_t lds = (size_t)(c->stack4 < WF_LDS_STACK ? c->stack4 : WF_LDS_STACK) * RT_BLOCK * sizeof(int);
     HIPCHK(hipMemsetAsync(W.count, 0, 4 * sizeof(uint32_t), c->stream));
@@ -585,9 +591,12 @@ extern "C" int rt_render_accumulate_window(rt_ctx* c, int w, int h, int x0, int 
     dim3 grid(n_tiles(win.z, win.w));
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     HIPCHK(hipEventRecord(e0, c->stream));
-    /* auto: the wavefront form pays off once traversal dominates (measured: 2.2x on the 1M-triangle scene,
-     * 0.8x on the final scene with its 11k BVH items and media in the world list) */
-    const bool wavefront = c->integrator == RT_INTEGRATOR_WAVEFRONT || (c->integrator == RT_INTEGRATOR_AUTO && c->n_bvh_items >= RT_WF_AUTO_ITEMS && c->stack4 <= WF_LDS_STACK + WF_OVF_STACK);
+    /* auto: the wavefront form pays off once traversal dominates.  Measured at 1920x1080 (tools/compare_integrators.py),
+     * wavefront / megakernel: 1M triangles 1.80, 200 k triangles 1.40, 20 k triangles 0.91, final scene (11 k or 1.4 k
+     * items, two BVH groups among eleven plain records) 1.17-1.20, Cornell + 1000-sphere cluster 1.12, 488 spheres in a
+     * world BVH 0.79, 16 boxes 0.33. */
+    const bool big = c->n_bvh_items >= RT_WF_AUTO_ITEMS || (c->n_bvh_items >= RT_WF_AUTO_ITEMS_LIST && c->n_wf_plain >= 4);
+    const bool wavefront = c->integrator == RT_INTEGRATOR_WAVEFRONT || (c->integrator == RT_INTEGRATOR_AUTO && big && c->stack4 <= WF_LDS_STACK + WF_OVF_STACK);
     if (wavefront) {
         int wrc = (c->features & ~RT_V_BVH_TRI) == 0 ? wf_run<RT_V_BVH_TRI>(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum)
                   : (c->features & RT_F_NOISE)       ? wf_run<RT_V_NOISE>(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum)

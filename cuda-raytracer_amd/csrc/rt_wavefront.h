@@ -42,6 +42,7 @@ struct WfState {
     const DProg* __restrict__ prog;
     const int* __restrict__ groups;
     int n_groups;
+    int refill_min;    /* idle lanes that make a refill (and its run over the plain records) worth while */
 };
 
 /* slot -> pixel: stream k of window pixel p is slot k * n_pixels + p; returns the pixel's index in the FRAME,
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(RT_BLOCK, WF_INTERSECT_WAVES) void wf_intersect_ker
         /* ---- refill: lanes without a ray take the next queue entries, a wave-wide batch at a time ---- */
         const unsigned long long need = __ballot(mode == WF_NEED);
         const int n_need = __popcll(need);
-        if (!drained && (n_need >= 16 || n_need == 64)) {
+        if (!drained && (n_need >= W.refill_min || n_need == 64)) {
             /* The wave owns a chunk [chunk_next, chunk_end) of the queue and hands its entries to idle
              * lanes; one returning atomic on the shared head per WF_CHUNK rays (a single word sustains
              * ~90 M dequeues/s on this chip, far below the ray rate if every refill paid one). */
