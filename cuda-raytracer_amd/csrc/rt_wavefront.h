@@ -7,10 +7,11 @@
  * ray), so a wave that only refills its lanes between bounces runs its traversal loop with a few lanes
  * live (measured 8 % in the node loop).  Here the path state lives in HBM and two kernels alternate:
  *
- *   wf_intersect  persistent waves; every lane is a small interpreter that advances ITS ray by one step
- *                 per trip (a scan record of the world list, a BVH node, or one leaf primitive) and, the
- *                 moment its ray is finished, takes the next ray from the queue — no lane waits for
- *                 another lane's ray.
+ *   wf_intersect  persistent waves; a batch of idle lanes takes rays from the queue, runs the plain records of
+ *                 the world list for them at once, and from then on every lane is a small interpreter that
+ *                 advances ITS ray through the list's BVH groups by one step per trip (a 4-wide node, or one
+ *                 leaf primitive); the moment its ray is finished the lane is free for the next batch — no
+ *                 lane waits for another lane's ray.
  *   wf_logic      one lane per queued path: rebuild the hit record, scatter, accumulate, start the next
  *                 sample of the slot when the path ends, and queue the slot again while it is alive.
  *
@@ -70,7 +71,6 @@ enum { WF_NEED = 0, WF_BVH = 2 };
 #ifndef WF_PRIM_BATCH
 #define WF_CHUNK 256         /* queue entries a wave claims per atomic */
 #define WF_PRIM_BATCH 20     /* lanes at a leaf that make a primitive step worth running */
-#define WF_SCAN_BATCH 16     /* lanes at a scan record */
 #define WF_NODE_LOW 16       /* fewer interior lanes than this: run whatever else is waiting */
 #endif
 

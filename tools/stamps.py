@@ -27,8 +27,8 @@ for q in range(6, 10):
 if os.environ.get("RT_INTEGRATOR") == "2" or (sc.flat.contents.n_bvh_nodes > 0 and os.environ.get("RT_INTEGRATOR") != "1"):
     d = [float(out[q] - base[q]) for q in range(8)]
     print("%s %dx%d@%d wavefront: %.1f ms, %.1f Mrays/s, rays %d" % (name, W, H, spp, c.last_render_ms, c.rays / c.last_render_ms / 1e3, c.rays))
-    print("  intersect: %.1f trips per ray-lane (trips*64/rays), busy lanes/trip %.1f, node %.1f prim %.1f scan %.1f; trips with scan %.2f, with prim %.2f; %.0f cycles/trip"
-          % (d[0] * 64 / c.rays, d[1] / d[0], d[2] / d[0], d[3] / d[0], d[4] / d[0], d[5] / d[0], d[6] / d[0], d[7] / d[0]))
+    print("  intersect: %.1f trips per ray-lane (trips*64/rays), busy lanes/trip %.1f, node lanes %.1f, prim lanes %.1f"
+          % (d[0] * 64 / c.rays, d[1] / d[0], d[2] / d[0], d[3] / d[0]))
     sys.exit(0)
 names = ["regen", "closest_hit", "rebuild", "ball", "tail", "scatter+rest"]
 tot = sum(out[:6]) or 1
