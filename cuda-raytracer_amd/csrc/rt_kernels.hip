@@ -482,17 +482,16 @@ static int wf_reserve(rt_ctx* c, size_t n_slots)
     if (n_slots > c->wf_slots_cap) {
         HIPCHK(hipStreamSynchronize(c->stream));
         if (c->wf_mem) { (void)hipFree(c->wf_mem); c->wf_mem = nullptr; c->wf_slots_cap = 0; }
-        const size_t bytes = n_slots * (6 * sizeof(float4) + 2 * sizeof(uint32_t)) + 256;
+        const size_t bytes = n_slots * (5 * sizeof(float4) + 2 * sizeof(uint32_t)) + 256;
         HIPCHK(hipMalloc(&c->wf_mem, bytes));
         c->wf_slots_cap = n_slots;
     }
-    /* carve: six float4 arrays, two queues, then the counters */
+    /* carve: five float4 arrays, two queues, then the counters */
     char* p = (char*)c->wf_mem;
     const size_t cap = c->wf_slots_cap;
     c->wf.ray_o = (float4*)p; p += cap * sizeof(float4);
     c->wf.ray_d = (float4*)p; p += cap * sizeof(float4);
     c->wf.att   = (float4*)p; p += cap * sizeof(float4);
-    c->wf.emi   = (float4*)p; p += cap * sizeof(float4);
     c->wf.sum   = (float4*)p; p += cap * sizeof(float4);
     c->wf.hit   = (float4*)p; p += cap * sizeof(float4);
     c->wf.queue[0] = (uint32_t*)p; p += cap * sizeof(uint32_t);

@@ -20,7 +20,7 @@
  * so the image is reproducible bit for bit from run to run.  The RNG is addressed by (pixel, sample,
  * bounce), so every sample's path is the same one the megakernel and the oracle trace.
  *
- * State traffic is 6 x 16 B per slot read and written about once per ray: ~200 B/ray, against the
+ * State traffic is 5 x 16 B per slot read and written about once per ray: ~170 B/ray, against the
  * ~2.8 KB/ray of BVH nodes and leaf rows the intersect kernel fetches on the triangle scene.
  */
 #ifndef RT_WAVEFRONT_H
@@ -31,7 +31,6 @@ struct WfState {
     float4* __restrict__ ray_o;   /* origin xyz, time */
     float4* __restrict__ ray_d;   /* direction xyz, bounce index (bits) */
     float4* __restrict__ att;     /* attenuation xyz, sample index in flight (bits) */
-    float4* __restrict__ emi;     /* emitted-so-far xyz, unused */
     float4* __restrict__ sum;     /* radiance sum of the slot's finished samples xyz, unused */
     float4* __restrict__ hit;     /* t, object, group, aux (bits) */
     uint32_t* __restrict__ queue[2];
@@ -155,7 +154,7 @@ __global__ __launch_bounds__(RT_BLOCK, wf_intersect_waves(F)) void wf_intersect_
                     rw.d = mk(d.x, d.y, d.z);
                     bounce = __float_as_uint(d.w);
                     g.pixel = wf_frame_pixel(W, slot);
-                    g.sample = __float_as_uint(W.att[slot].w);
+                    if (F & RT_F_MEDIA) g.sample = __float_as_uint(W.att[slot].w);   /* the RNG address is only read by media */
                     best.t = FLT_MAX; best.obj = -1; best.grp = -1; best.aux = 0;
                     ++n_rays;
                     /* the plain records of the world list, for all the lanes of this batch together (one scalar
@@ -251,7 +250,7 @@ __global__ __launch_bounds__(RT_BLOCK, wf_intersect_waves(F)) void wf_intersect_
 /* ---------------------------------------------------------------------- logic -- */
 template <uint32_t F>
 __device__ __forceinline__ void wf_start_sample(const DScene& S, const WfState& W, uint32_t slot, uint32_t sample, int Wd, int Hd,
-                                                uint32_t k0, uint32_t k1, float4& o4, float4& d4, float4& a4, float4& e4)
+                                                uint32_t k0, uint32_t k1, float4& o4, float4& d4, float4& a4)
 {
     uint32_t ui, uj;
     const uint32_t pixel = wf_frame_pixel(W, slot, ui, uj);
@@ -265,7 +264,6 @@ __device__ __forceinline__ void wf_start_sample(const DScene& S, const WfState& 
     o4 = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.time);
     d4 = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(0u));
     a4 = make_float4(1.f, 1.f, 1.f, __uint_as_float(sample));
-    e4 = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 /* wave-aggregated append of `slot` to a queue */
@@ -296,9 +294,9 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_init_kernel(DScene S, WfState W, 
         const uint32_t s = s_begin + k;
         W.sum[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (s < s_end && max_depth > 0) {
-            float4 o4, d4, a4, e4;
-            wf_start_sample<F>(S, W, slot, s, Wd, Hd, k0, k1, o4, d4, a4, e4);
-            W.ray_o[slot] = o4; W.ray_d[slot] = d4; W.att[slot] = a4; W.emi[slot] = e4;
+            float4 o4, d4, a4;
+            wf_start_sample<F>(S, W, slot, s, Wd, Hd, k0, k1, o4, d4, a4);
+            W.ray_o[slot] = o4; W.ray_d[slot] = d4; W.att[slot] = a4;
             alive = true;
         }
     }
@@ -320,6 +318,10 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_logic_kernel(DScene S, WfState W,
     const uint32_t slot = active ? W.queue[qi][e] : 0u;
 
     DRay ray = {mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f), 0.f};
+    /* colour()'s running emission L (main.cu:64) is not part of the stored state: only DiffuseLight emits
+     * (Material.cuh:121-131; Material::emitted returns black) and it never scatters, so L is still zero
+     * whenever a path goes on to its next bounce (an attenuation that has overflowed to inf, which takes albedos
+     * above 1, would make it NaN in the megakernel: 0 * inf) */
     V3 att = mk(1.f, 1.f, 1.f), emi = mk(0.f, 0.f, 0.f);
     HitLite hl = {FLT_MAX, -1, -1, 0};
     uint32_t sample = 0;
@@ -327,11 +329,10 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_logic_kernel(DScene S, WfState W,
     PathRng g;
     rng_start(g, k0, k1, 0u, 0u);
     if (active) {
-        const float4 o = W.ray_o[slot], d = W.ray_d[slot], a = W.att[slot], em = W.emi[slot], h = W.hit[slot];
+        const float4 o = W.ray_o[slot], d = W.ray_d[slot], a = W.att[slot], h = W.hit[slot];
         ray.o = mk(o.x, o.y, o.z); ray.time = o.w; ray.d = mk(d.x, d.y, d.z);
         depth = (int)__float_as_uint(d.w);
         att = mk(a.x, a.y, a.z); sample = __float_as_uint(a.w);
-        emi = mk(em.x, em.y, em.z);
         hl.t = h.x; hl.obj = __float_as_int(h.y); hl.grp = __float_as_int(h.z); hl.aux = __float_as_int(h.w);
         rng_start(g, k0, k1, wf_frame_pixel(W, slot), sample);
     }
@@ -382,7 +383,6 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_logic_kernel(DScene S, WfState W,
             W.ray_o[slot] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.time);
             W.ray_d[slot] = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float((uint32_t)depth));
             W.att[slot] = make_float4(att.x, att.y, att.z, __uint_as_float(sample));
-            W.emi[slot] = make_float4(emi.x, emi.y, emi.z, 0.f);
             alive = true;
         } else {
             float4 sm = W.sum[slot];
@@ -390,9 +390,9 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_logic_kernel(DScene S, WfState W,
             W.sum[slot] = sm;
             const uint32_t next = sample + W.streams;
             if (next < s_end && next > sample) {
-                float4 o4, d4, a4, e4;
-                wf_start_sample<F>(S, W, slot, next, Wd, Hd, k0, k1, o4, d4, a4, e4);
-                W.ray_o[slot] = o4; W.ray_d[slot] = d4; W.att[slot] = a4; W.emi[slot] = e4;
+                float4 o4, d4, a4;
+                wf_start_sample<F>(S, W, slot, next, Wd, Hd, k0, k1, o4, d4, a4);
+                W.ray_o[slot] = o4; W.ray_d[slot] = d4; W.att[slot] = a4;
                 alive = true;
             }
         }
