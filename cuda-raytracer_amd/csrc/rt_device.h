@@ -125,6 +125,28 @@ __device__ __forceinline__ bool sphere_t(V3 centre, float radius, const DRay& r,
     }
     return false;
 }
+/* The two boundary queries of ConstantMedium::hit (Volumes.cuh:29-30) against a Sphere boundary: the roots do not
+ * depend on the query's range, so hit(r, -FLT_MAX, FLT_MAX) and hit(r, t1 + .0001f, FLT_MAX) share one
+ * discriminant, one square root and the two divisions.  Returns the number of queries that hit (0, 1, 2). */
+__device__ __forceinline__ int sphere_two_t(V3 centre, float radius, const DRay& r, float& t1, float& t2)
+{
+    V3 oc = r.o - centre;
+    float a = dot(r.d, r.d);
+    float b = 2.f * dot(oc, r.d);
+    float c = dot(oc, oc) - radius * radius;
+    float discrim = b * b - 4.f * a * c;
+    if (!(discrim > 0)) return 0;
+    const float sq = sqrtf(discrim);
+    const float lo = (-b - sq) / (2 * a), hi = (-b + sq) / (2 * a);
+    if (lo < FLT_MAX && lo > -FLT_MAX) t1 = lo;
+    else if (hi < FLT_MAX && hi > -FLT_MAX) t1 = hi;
+    else return 0;
+    const float t0 = t1 + .0001f;
+    if (lo < FLT_MAX && lo > t0) t2 = lo;
+    else if (hi < FLT_MAX && hi > t0) t2 = hi;
+    else return 1;
+    return 2;
+}
 __device__ __forceinline__ V3 moving_centre(const float* f, float time)
 {
     V3 c0 = ld3(f), c1 = ld3(f + 3);
@@ -333,6 +355,10 @@ __device__ __forceinline__ bool medium_t(const DScene& S, const DObj& o, const D
         DRay rb = r;
         if (F & RT_F_XFORM) apply_chain(S, b, rb);
         if (box_two_t(b.f, rb, t1, t2) < 2) return false;
+    } else if ((F & RT_F_SPHERE) && obj_type(b.head) == RT_OBJ_SPHERE) {
+        DRay rb = r;
+        if (F & RT_F_XFORM) apply_chain(S, b, rb);
+        if (sphere_two_t(ld3(b.f), b.f[3], rb, t1, t2) < 2) return false;
     } else {
         if (!leaf_t<F>(S, b, r, -FLT_MAX, FLT_MAX, t1, unused)) return false;
         if (!leaf_t<F>(S, b, r, t1 + .0001f, FLT_MAX, t2, unused)) return false;
