@@ -379,6 +379,26 @@ extern "C" int rt_flat_program(const rt_flat_scene* flat, uint32_t* out_words, i
     return (int)prog.size();
 }
 
+extern "C" int rt_flat_program_split(const rt_flat_scene* flat, uint32_t* out_words, int cap_records, int32_t* out_groups, int cap_groups,
+                                     int* n_groups)
+{
+    std::string why;
+    if (!flat || cap_records < 0 || cap_groups < 0 || (cap_records && !out_words) || (cap_groups && !out_groups) || !n_groups) {
+        rt_set_error("rt_flat_program_split: bad arguments");
+        return RT_ERR_ARG;
+    }
+    if (!rt_validate_scene(flat, why, nullptr)) { rt_set_error("rt_flat_program_split: invalid scene: " + why); return RT_ERR_ARG; }
+    std::vector<DProg> prog, plain;
+    std::vector<int> groups;
+    rt_pack_program(flat, prog, &plain, &groups);
+    const size_t n = plain.size() < (size_t)cap_records ? plain.size() : (size_t)cap_records;
+    if (n) std::memcpy(out_words, plain.data(), n * sizeof(DProg));
+    const size_t g = groups.size() < (size_t)cap_groups ? groups.size() : (size_t)cap_groups;
+    if (g) std::memcpy(out_groups, groups.data(), g * sizeof(int32_t));
+    *n_groups = (int)groups.size();
+    return (int)plain.size();
+}
+
 extern "C" int rt_flat_bvh_stats(const rt_flat_scene* flat, int* nodes2, int* depth2, int* nodes4, int* depth4)
 {
     std::string why;

@@ -142,6 +142,11 @@ uint32_t rt_flat_features(const rt_flat_scene* flat);
  * HitableList::list, HitableList.cuh:17-32): writes up to cap records of 8 words and returns how many the
  * scene has (terminators included), or a negative rt_status */
 int  rt_flat_program(const rt_flat_scene* flat, uint32_t* out_words, int cap_records);
+/* the same list as the wavefront integrator takes it: the plain records without the BVH groups (return value =
+ * their count, terminators included), and the BVH groups' object indices in list order (*n_groups; the world
+ * itself when it has a BVH of its own) */
+int  rt_flat_program_split(const rt_flat_scene* flat, uint32_t* out_words, int cap_records, int32_t* out_groups, int cap_groups,
+                           int* n_groups);
 /* sizes of the device BVHs: two-box nodes, four-box nodes, traversal stack entries each needs */
 int  rt_flat_bvh_stats(const rt_flat_scene* flat, int* nodes2, int* depth2, int* nodes4, int* depth4);
 

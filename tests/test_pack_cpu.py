@@ -99,3 +99,38 @@ def test_scene_without_bvh(binding):
     n2, d2, n4, d4 = C.c_int(7), C.c_int(7), C.c_int(7), C.c_int(7)
     assert binding.lib().rt_flat_bvh_stats(sc.flat, C.byref(n2), C.byref(d2), C.byref(n4), C.byref(d4)) == 0
     assert (n2.value, d2.value, n4.value, d4.value) == (0, 0, 0, 0)
+
+
+def split_program(binding, sc):
+    lib = binding.lib()
+    ng = C.c_int()
+    n = lib.rt_flat_program_split(sc.flat, None, 0, None, 0, C.byref(ng))
+    assert n >= 2
+    buf = (C.c_uint32 * (8 * n))()
+    groups = (C.c_int32 * max(1, ng.value))()
+    assert lib.rt_flat_program_split(sc.flat, buf, n, groups, ng.value, C.byref(ng)) == n
+    return np.frombuffer(buf, dtype=np.uint32).reshape(n, 8).copy(), list(groups)[:ng.value]
+
+
+@pytest.mark.parametrize("name,param", [("final", 12), ("cornell_cluster", 0), ("tri_mesh", 3000), ("random_spheres", 0), ("cornell", 0), ("kat", 0)])
+def test_program_split_for_the_wavefront_form(binding, name, param):
+    """the wavefront integrator runs the plain records when it hands a ray to a lane and then walks the BVH groups:
+    together the two parts are the whole list, order kept within each"""
+    sc = binding.Scene(name, 64, 64, param)
+    full, _ = program(binding, sc)
+    plain, groups = split_program(binding, sc)
+    fl = sc.flat.contents
+    world = fl.objects[fl.world]
+    is_bvh_group = lambda oi: fl.objects[oi].type == 8 and fl.objects[oi].bvh_root >= 0
+    if world.bvh_root >= 0:
+        assert groups == [fl.world] and [int(k) & 0xff for k in plain[:, 0]] == [P_END, P_END]
+        return
+    want_groups = [int(r[1]) for r in full if (int(r[0]) & 0xff) == P_GENERIC and is_bvh_group(int(r[1]))]
+    assert groups == want_groups
+    kept = [r for r in full if not ((int(r[0]) & 0xff) == P_GENERIC and is_bvh_group(int(r[1])))]
+    assert np.array_equal(plain, np.array(kept, dtype=np.uint32))
+    assert not any((int(r[0]) & 0xff) == P_GENERIC and is_bvh_group(int(r[1])) for r in plain)
+    if name in ("final", "cornell_cluster", "tri_mesh", "kat"):      # kat: its surfaces were gathered into one BVH group
+        assert len(groups) >= 1
+    if name == "cornell":
+        assert groups == []
