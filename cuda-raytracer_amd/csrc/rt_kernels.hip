@@ -37,8 +37,13 @@
 #define RT_WF_AUTO_ITEMS 65536        /* BVH items from which RT_INTEGRATOR_AUTO takes the wavefront form ... */
 #define RT_WF_AUTO_ITEMS_LIST 1000    /* ... or from this many when the world list also holds >= 4 plain records */
 #endif
+/* Paths the wavefront integrator keeps in flight (88 B of HBM each: 11.3 GB at this default).  Measured on the
+ * 1M-triangle scene at 1080p x 128 spp / the final scene at 4K x 128 spp, Grays/s: 8 M slots 1.38 / 1.52,
+ * 16 M 1.52 / 1.64, 32 M 1.62 / 1.75, 64 M 1.75 / 1.83, 128 M 1.81 / 1.89, 256 M 1.84 / 1.94: every launch ends with a
+ * drain in which the waves wait for their last rays, and the more rays a launch carries the less that costs.
+ * The environment variable RT_WF_SLOTS overrides it; an allocation that fails is retried at half the size. */
 #ifndef RT_WF_SLOTS
-#define RT_WF_SLOTS (1u << 23)
+#define RT_WF_SLOTS (1u << 27)
 #endif
 #define RT_N_COUNTERS 16        /* rays, samples, then diagnostic slots */
 /* waves per SIMD each render-kernel variant is compiled for (its VGPR budget).  Measured on the Cornell
@@ -282,6 +287,7 @@ struct rt_ctx {
     WfState wf = {};
     void* wf_mem = nullptr;
     size_t wf_slots_cap = 0;
+    size_t wf_slots_target = RT_WF_SLOTS;   /* paths to keep in flight */
     uint32_t* wf_host_count = nullptr;   /* pinned */
     int stack_depth = 0;      /* LDS stack entries per lane the uploaded BVHs need */
     int stack4 = 1;           /* entries a traversal of the 4-wide trees can need (3 per level) */
@@ -314,6 +320,7 @@ extern "C" int rt_ctx_create(int device, void* stream, rt_ctx** out)
     HIPCHK(hipSetDevice(device));
     rt_ctx* c = new rt_ctx();
     c->device = device;
+    if (const char* e = std::getenv("RT_WF_SLOTS")) { const long long v = std::atoll(e); if (v > 0) c->wf_slots_target = (size_t)v; }
     if (stream) c->stream = (hipStream_t)stream;
     else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; rt_set_error("hipStreamCreate failed"); return RT_ERR_HIP; }
@@ -483,7 +490,12 @@ static int wf_reserve(rt_ctx* c, size_t n_slots)
         HIPCHK(hipStreamSynchronize(c->stream));
         if (c->wf_mem) { (void)hipFree(c->wf_mem); c->wf_mem = nullptr; c->wf_slots_cap = 0; }
         const size_t bytes = n_slots * (5 * sizeof(float4) + 2 * sizeof(uint32_t)) + 256;
-        HIPCHK(hipMalloc(&c->wf_mem, bytes));
+        if (hipMalloc(&c->wf_mem, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            c->wf_mem = nullptr;
+            rt_set_error("wavefront integrator: no memory for the path state");
+            return RT_ERR_HIP;
+        }
         c->wf_slots_cap = n_slots;
     }
     /* carve: five float4 arrays, two queues, then the counters */
@@ -507,11 +519,18 @@ static int wf_run(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t s1, u
     const uint32_t n_pixels = (uint32_t)win.z * (uint32_t)win.w;
     /* about RT_WF_SLOTS paths in flight (each persistent lane should see many rays per launch, so that the
      * drain at the end of a launch, when the queue is empty and waves wait for their last rays, stays small): K sample streams per pixel, never more than there are samples */
-    uint32_t streams = (RT_WF_SLOTS + n_pixels - 1) / n_pixels;
+    uint32_t streams = (uint32_t)((c->wf_slots_target + n_pixels - 1) / n_pixels);
     if (streams > s1 - s0) streams = s1 - s0;
     if (streams < 1) streams = 1;
-    const size_t n_slots = (size_t)n_pixels * streams;
+    while ((size_t)n_pixels * streams > 0xffffffffull) streams = (streams + 1) / 2;    /* slot indices are 32-bit */
+    size_t n_slots = (size_t)n_pixels * streams;
     int rc = wf_reserve(c, n_slots);
+    while (rc && streams > 1) {            /* no room for that many paths: halve, and remember */
+        streams = (streams + 1) / 2;
+        n_slots = (size_t)n_pixels * streams;
+        c->wf_slots_target = n_slots;
+        rc = wf_reserve(c, n_slots);
+    }
     if (rc) return rc;
     WfState& W = c->wf;
     W.n_slots = (uint32_t)n_slots; W.n_pixels = n_pixels; W.streams = streams;
