@@ -542,6 +542,10 @@ static int wf_run(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t s1, u
     if (c->stack4 > WF_LDS_STACK + WF_OVF_STACK) { rt_set_error("wavefront integrator: BVH deeper than its traversal stack"); return RT_ERR_UNSUPPORTED; }
     const size_t lds = (size_t)(c->stack4 < WF_LDS_STACK ? c->stack4 : WF_LDS_STACK) * RT_BLOCK * sizeof(int);
     HIPCHK(hipMemsetAsync(W.count, 0, 4 * sizeof(uint32_t), c->stream));
+    if (max_depth > 0) {       /* the first queue is every slot, in order (wf_init_kernel) */
+        c->wf_host_count[3] = (uint32_t)n_slots;
+        HIPCHK(hipMemcpyAsync(W.count, &c->wf_host_count[3], sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    }
     const unsigned all_blocks = (unsigned)((n_slots + RT_BLOCK - 1) / RT_BLOCK);
     wf_init_kernel<V><<<dim3(all_blocks), RT_BLOCK, 0, c->stream>>>(c->ds, W, w, h, s0, s1, k0, k1, max_depth, c->d_counters);
     HIPCHK(hipGetLastError());
@@ -559,11 +563,12 @@ static int wf_run(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t s1, u
             wf_reset_kernel<<<1, 1, 0, c->stream>>>(W.count, cur ^ 1);
             unsigned blocks = (known + RT_BLOCK - 1) / RT_BLOCK;
             unsigned iblocks = blocks < 2048u ? blocks : 2048u;
+            const unsigned lblocks = (known + RT_BLOCK * WF_LOGIC_TILES - 1) / (RT_BLOCK * WF_LOGIC_TILES);
             wf_intersect_kernel<(V & ~RT_F_NOISE)><<<dim3(iblocks), RT_BLOCK, lds, c->stream>>>(c->ds, W, cur, k0, k1, c->d_counters);   /* reads no texture */
             if (background == RT_BG_BLACK)
-                wf_logic_kernel<V, RT_BG_BLACK><<<dim3(blocks), RT_BLOCK, 0, c->stream>>>(c->ds, W, cur, w, h, s1, k0, k1, max_depth);
+                wf_logic_kernel<V, RT_BG_BLACK><<<dim3(lblocks), RT_BLOCK, 0, c->stream>>>(c->ds, W, cur, w, h, s1, k0, k1, max_depth);
             else
-                wf_logic_kernel<V, RT_BG_SKY><<<dim3(blocks), RT_BLOCK, 0, c->stream>>>(c->ds, W, cur, w, h, s1, k0, k1, max_depth);
+                wf_logic_kernel<V, RT_BG_SKY><<<dim3(lblocks), RT_BLOCK, 0, c->stream>>>(c->ds, W, cur, w, h, s1, k0, k1, max_depth);
             cur ^= 1;
         }
         HIPCHK(hipGetLastError());

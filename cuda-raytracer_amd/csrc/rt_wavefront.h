@@ -68,7 +68,7 @@ constexpr int wf_intersect_waves(uint32_t F) { return (F & ~(RT_F_BVH | RT_F_TRI
 #define WF_LDS_STACK 20      /* traversal-stack entries per lane kept in LDS; deeper ones go to scratch */
 #define WF_OVF_STACK 44      /* entries of the scratch overflow: 3 per level of a 4-wide tree, rarely reached */
 #ifndef WF_PRIM_BATCH
-#define WF_CHUNK 256         /* queue entries a wave claims per atomic */
+#define WF_CHUNK 1024        /* queue entries a wave claims per atomic, at most */
 #define WF_PRIM_BATCH 20     /* lanes at a leaf that make a primitive step worth running */
 #define WF_NODE_LOW 16       /* fewer interior lanes than this: run whatever else is waiting */
 #endif
@@ -282,40 +282,35 @@ __device__ __forceinline__ void wf_push(uint32_t* __restrict__ queue, uint32_t* 
     }
 }
 
-/* first launch of a render call: every slot starts its first sample (or stays dead) */
+/* first launch of a render call: every slot starts its first sample.  There are never more streams than samples,
+ * so every slot is alive (unless max_depth is 0) and the first queue is simply the slots in order: no atomics
+ * (one per wave on a single word took 11 ms for 66 M slots); the host sets its length. */
 template <uint32_t F>
 __global__ __launch_bounds__(RT_BLOCK) void wf_init_kernel(DScene S, WfState W, int Wd, int Hd, uint32_t s_begin, uint32_t s_end,
                                                            uint32_t k0, uint32_t k1, int max_depth, unsigned long long* __restrict__ counters)
 {
     const uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
-    bool alive = false;
     if (slot < W.n_slots) {
         const uint32_t k = slot / W.n_pixels;
         const uint32_t s = s_begin + k;
         W.sum[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (s < s_end && max_depth > 0) {
+        if (max_depth > 0) {
             float4 o4, d4, a4;
             wf_start_sample<F>(S, W, slot, s, Wd, Hd, k0, k1, o4, d4, a4);
             W.ray_o[slot] = o4; W.ray_d[slot] = d4; W.att[slot] = a4;
-            alive = true;
+            W.queue[0][slot] = slot;
         }
     }
-    wf_push(W.queue[0], &W.count[0], alive, slot);
     /* samples counter: every sample of the range is rendered (black when max_depth is 0) */
     if (slot == 0) atomicAdd(&counters[1], (unsigned long long)W.n_pixels * (unsigned long long)(s_end - s_begin));
 }
 
+/* one queued path through one bounce; returns whether its slot goes on (with the same path or its next sample).
+ * Called by all 64 lanes of a wave together (the ball draw is wave-wide). */
 template <uint32_t F, int BG>
-__global__ __launch_bounds__(RT_BLOCK) void wf_logic_kernel(DScene S, WfState W, int qi, int Wd, int Hd, uint32_t s_end,
-                                                            uint32_t k0, uint32_t k1, int max_depth)
+__device__ __forceinline__ bool wf_logic_one(const DScene& S, const WfState& W, bool active, uint32_t slot, int Wd, int Hd, uint32_t s_end,
+                                             uint32_t k0, uint32_t k1, int max_depth, int* slots)
 {
-    __shared__ int slot_mem[RT_BLOCK];
-    int* slots = slot_mem + (threadIdx.x & ~63u);
-    const uint32_t n_queue = W.count[qi];
-    const uint32_t e = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (blockIdx.x * RT_BLOCK >= n_queue) return;             /* whole block beyond the queue */
-    const bool active = e < n_queue;
-    const uint32_t slot = active ? W.queue[qi][e] : 0u;
 
     DRay ray = {mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f), 0.f};
     /* colour()'s running emission L (main.cu:64) is not part of the stored state: only DiffuseLight emits
@@ -397,8 +392,59 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_logic_kernel(DScene S, WfState W,
             }
         }
     }
-    wf_push(W.queue[qi ^ 1], &W.count[qi ^ 1], alive, slot);
+    return alive;
 }
+
+/* A block runs WF_LOGIC_TILES consecutive tiles of 256 queue entries and appends its survivors to the next queue with
+ * ONE atomic, in entry order (so the queue stays sorted by slot and the state accesses stay nearly coalesced).  With
+ * one atomic per wave the kernel was bound by that single word: 7.3 M returning atomics per call of the 1M-triangle
+ * bench at the ~90 M/s a word sustains is 81 of its 86 ms. */
+#define WF_LOGIC_TILES 4
+template <uint32_t F, int BG>
+__global__ __launch_bounds__(RT_BLOCK) void wf_logic_kernel(DScene S, WfState W, int qi, int Wd, int Hd, uint32_t s_end,
+                                                            uint32_t k0, uint32_t k1, int max_depth)
+{
+    __shared__ int slot_mem[RT_BLOCK];
+    __shared__ uint32_t keep_slot[WF_LOGIC_TILES][RT_BLOCK];
+    __shared__ unsigned long long keep_mask[WF_LOGIC_TILES][RT_BLOCK / 64];
+    __shared__ uint32_t base_s;
+    int* slots = slot_mem + (threadIdx.x & ~63u);
+    const uint32_t n_queue = W.count[qi];
+    const uint32_t first = blockIdx.x * (RT_BLOCK * WF_LOGIC_TILES);
+    if (first >= n_queue) return;                             /* whole block beyond the queue */
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    for (int tile = 0; tile < WF_LOGIC_TILES; ++tile) {
+        const uint32_t e = first + tile * RT_BLOCK + threadIdx.x;
+        const bool active = e < n_queue;
+        const uint32_t slot = active ? W.queue[qi][e] : 0u;
+        bool alive = false;
+        if (first + tile * RT_BLOCK < n_queue)                /* block-uniform: skip tiles beyond the queue */
+            alive = wf_logic_one<F, BG>(S, W, active, slot, Wd, Hd, s_end, k0, k1, max_depth, slots);
+        keep_slot[tile][threadIdx.x] = slot;
+        const unsigned long long m = __ballot(alive);
+        if (lane == 0) keep_mask[tile][wave] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int t = 0; t < WF_LOGIC_TILES; ++t)
+            for (int w = 0; w < RT_BLOCK / 64; ++w) total += (uint32_t)__popcll(keep_mask[t][w]);
+        base_s = total ? atomicAdd(&W.count[qi ^ 1], total) : 0u;
+    }
+    __syncthreads();
+    uint32_t* __restrict__ out = W.queue[qi ^ 1];
+    uint32_t before = base_s;                                 /* survivors of earlier (tile, wave) pairs */
+    for (int t = 0; t < WF_LOGIC_TILES; ++t)
+        for (int w = 0; w < RT_BLOCK / 64; ++w) {
+            const unsigned long long m = keep_mask[t][w];
+            if (w == wave && ((m >> lane) & 1ull)) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                out[before + rank] = keep_slot[t][threadIdx.x];
+            }
+            before += (uint32_t)__popcll(m);
+        }
+}
+
 
 /* accum[pixel] += the K stream sums of the pixel, in stream order */
 __global__ __launch_bounds__(RT_BLOCK) void wf_finalize_kernel(WfState W, float* __restrict__ accum)
