@@ -399,7 +399,9 @@ __device__ __forceinline__ bool wf_logic_one(const DScene& S, const WfState& W, 
  * ONE atomic, in entry order (so the queue stays sorted by slot and the state accesses stay nearly coalesced).  With
  * one atomic per wave the kernel was bound by that single word: 7.3 M returning atomics per call of the 1M-triangle
  * bench at the ~90 M/s a word sustains is 81 of its 86 ms. */
+#ifndef WF_LOGIC_TILES
 #define WF_LOGIC_TILES 4
+#endif
 template <uint32_t F, int BG>
 __global__ __launch_bounds__(RT_BLOCK) void wf_logic_kernel(DScene S, WfState W, int qi, int Wd, int Hd, uint32_t s_end,
                                                             uint32_t k0, uint32_t k1, int max_depth)
