@@ -538,7 +538,11 @@ static int wf_run(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t s1, u
     W.prog = (const DProg*)c->d_prog_wf; W.groups = (const int*)c->d_wf_groups; W.n_groups = c->n_wf_groups;
     /* a refill runs the plain records of the world list for the lanes it fills: the longer that list, the more
      * lanes it should wait for (measured: 1 record -> 32 best, the final scene's 11 -> 48) */
+#ifdef WF_REFILL_SHORT
+    W.refill_min = c->n_wf_plain <= 4 ? WF_REFILL_SHORT : WF_REFILL_LONG;      /* tuning builds */
+#else
     W.refill_min = c->n_wf_plain <= 4 ? 32 : 48;
+#endif
     if (c->stack4 > WF_LDS_STACK + WF_OVF_STACK) { rt_set_error("wavefront integrator: BVH deeper than its traversal stack"); return RT_ERR_UNSUPPORTED; }
     const size_t lds = (size_t)(c->stack4 < WF_LDS_STACK ? c->stack4 : WF_LDS_STACK) * RT_BLOCK * sizeof(int);
     HIPCHK(hipMemsetAsync(W.count, 0, 4 * sizeof(uint32_t), c->stream));
