@@ -34,8 +34,7 @@
 #define RT_V_BVH_TRI      (RT_F_BVH | RT_F_TRI | RT_F_PLANAR)                          /* triangle mesh + area light */
 #define RT_V_NOISE        (RT_F_ALL | RT_F_NOISE)                                      /* anything with a NoiseTexture */
 #ifndef RT_WF_AUTO_ITEMS
-#define RT_WF_AUTO_ITEMS 65536        /* BVH items from which RT_INTEGRATOR_AUTO takes the wavefront form ... */
-#define RT_WF_AUTO_ITEMS_LIST 1000    /* ... or from this many when the world list also holds >= 4 plain records */
+#define RT_WF_AUTO_ITEMS 128          /* BVH items from which RT_INTEGRATOR_AUTO takes the wavefront form */
 #endif
 /* Paths the wavefront integrator keeps in flight (88 B of HBM each: 11.3 GB at this default).  Measured on the
  * 1M-triangle scene at 1080p x 128 spp / the final scene at 4K x 128 spp, Grays/s: 8 M slots 1.38 / 1.52,
@@ -618,11 +617,10 @@ extern "C" int rt_render_accumulate_window(rt_ctx* c, int w, int h, int x0, int 
     dim3 grid(n_tiles(win.z, win.w));
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     HIPCHK(hipEventRecord(e0, c->stream));
-    /* auto: the wavefront form pays off once traversal dominates.  Measured at 1920x1080 (tools/compare_integrators.py),
-     * wavefront / megakernel: 1M triangles 1.80, 200 k triangles 1.40, 20 k triangles 0.91, final scene (11 k or 1.4 k
-     * items, two BVH groups among eleven plain records) 1.17-1.20, Cornell + 1000-sphere cluster 1.12, 488 spheres in a
-     * world BVH 0.79, 16 boxes 0.33. */
-    const bool big = c->n_bvh_items >= RT_WF_AUTO_ITEMS || (c->n_bvh_items >= RT_WF_AUTO_ITEMS_LIST && c->n_wf_plain >= 4);
+    /* auto: the wavefront form pays off as soon as a BVH is traversed.  Measured at 1920x1080 (tools/compare_integrators.py),
+     * wavefront / megakernel: 1M triangles 2.92, 200 k 2.27, 20 k 1.70; final scene (11 k or 1.4 k items) 2.18-2.62; Cornell +
+     * 1000-sphere cluster 2.18; 488 spheres in a world BVH 1.59; 16 boxes 0.62; no BVH at all (Cornell) 0.30. */
+    const bool big = c->n_bvh_items >= RT_WF_AUTO_ITEMS;
     const bool wavefront = c->integrator == RT_INTEGRATOR_WAVEFRONT || (c->integrator == RT_INTEGRATOR_AUTO && big && c->stack4 <= WF_LDS_STACK + WF_OVF_STACK);
     if (wavefront) {
         int wrc = (c->features & ~RT_V_BVH_TRI) == 0 ? wf_run<RT_V_BVH_TRI>(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum)

@@ -12,7 +12,7 @@ B = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(B)
 W, H, spp = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (1920, 1080, 32)
 ctx = B.Context(0)
-for name, param in [("bvh_boxes", 0), ("random_spheres", 0), ("cornell_cluster", 0), ("final", 20), ("final", 100), ("tri_mesh", 20000),
+for name, param in [("cornell", 0), ("cornell_smoke", 0), ("bvh_boxes", 0), ("random_spheres", 0), ("cornell_cluster", 0), ("final", 20), ("final", 100), ("tri_mesh", 20000),
                     ("tri_mesh", 200000), ("tri_mesh", 1000000)]:
     sc = B.Scene(name, W, H, param)
     ctx.upload(sc)
