@@ -528,6 +528,9 @@ bool lower(Hitable* world, const Camera* cam, const LowerOptions& opt, FlatScene
 }
 
 /* ------------------------------------------------------------ BVH builder -- */
+#ifndef RT_BVH_BINS
+#define RT_BVH_BINS 16     /* SAH bins per axis */
+#endif
 namespace {
 struct Item { Box3 box; float cen[3]; int obj; };
 
@@ -552,7 +555,7 @@ struct Builder {
         for (int i = first; i < first + count; ++i) { bb.grow(items[i].box); cb.grow(items[i].cen); }
         if (count <= leaf_size) { set_node(node, bb, (uint32_t)(item_base + first), (uint32_t)count); return; }
 
-        const int NB = 16;
+        const int NB = RT_BVH_BINS;
         int best_axis = -1, best_split = -1;
         float best_cost = FLT_MAX;
         for (int ax = 0; ax < 3; ++ax) {
