@@ -415,3 +415,26 @@ def test_windows_tile_the_frame(binding, gpu_ctx, name, param, integrator):
                 gpu_ctx.render_window(acc, W, H, bad, 0, 1, 419, 100, sc.background)
     finally:
         gpu_ctx.set_integrator(0)
+
+
+def test_wavefront_with_a_small_path_pool(binding, gpu_ctx, monkeypatch):
+    """RT_WF_SLOTS bounds the paths in flight: with fewer slots than samples a slot runs its samples one after the other
+    (streams < spp); the image is the megakernel's up to the grouping of the per-pixel sums"""
+    import torch
+    W, H, spp = 48, 40, 24
+    sc = binding.Scene("final", W, H, 8)
+    gpu_ctx.upload(sc)
+    ref = render_gpu(gpu_ctx, binding, sc, W, H, 1, 1 + spp, 31, integrator="megakernel")
+    for slots in (W * H, 3 * W * H + 17, 5000 * W * H):            # 1 stream, 4 streams (rounded up), one per sample
+        monkeypatch.setenv("RT_WF_SLOTS", str(slots))
+        ctx = binding.Context(0)
+        try:
+            ctx.upload(sc)
+            got = render_gpu(ctx, binding, sc, W, H, 1, 1 + spp, 31, integrator="wavefront")
+            c = ctx.counters()
+            assert c.samples == W * H * spp
+            assert torch.allclose(got, ref, rtol=2e-5, atol=1e-5), slots
+            if slots == W * H:
+                assert torch.equal(got, ref)        # one stream: the megakernel's summation order, hence its bits
+        finally:
+            ctx.close()
