@@ -51,7 +51,10 @@
  * launch against 26 MB of algorithmic bytes, so the spill-free 5 is used.  The larger variants spill earlier. */
 constexpr int rt_render_waves(uint32_t F)
 {
-    return (F & RT_F_BVH) ? 3 : ((F & ~(RT_F_PLANAR | RT_F_XFORM)) == 0 ? 5 : 4);
+#ifndef RT_PLANAR_WAVES
+#define RT_PLANAR_WAVES 5
+#endif
+    return (F & RT_F_BVH) ? 3 : ((F & ~(RT_F_PLANAR | RT_F_XFORM)) == 0 ? RT_PLANAR_WAVES : 4);
 }
 
 /* Diagnostic build only (-DRT_STAMPS, tools/diag): shader-clock time of each section of the render
@@ -132,42 +135,76 @@ __global__ __launch_bounds__(RT_BLOCK) void trace_primary_kernel(DScene S, int W
 }
 
 template <uint32_t F, int BG>
-__global__ __launch_bounds__(RT_BLOCK, rt_render_waves(F)) void render_kernel(DScene S, int W, int H, int4 win, uint32_t s_begin, uint32_t s_end,
+__global__ __launch_bounds__(RT_BLOCK, rt_render_waves(F)) void render_kernel(DScene S, int W, int H, int4 win, uint32_t s_first, uint32_t s_last,
                                                            uint32_t k0, uint32_t k1, int max_depth,
                                                            float* __restrict__ accum,
-                                                           unsigned long long* __restrict__ counters)
+                                                           unsigned long long* __restrict__ counters,
+                                                           uint32_t per_group, float* __restrict__ partial,
+                                                           uint32_t n_groups, uint32_t tile_step)
 {
+    /* The call's sample range is cut into n_groups runs of per_group samples (rt_render_accumulate).  Block B
+     * renders run k of tile (B + k * tile_step) mod n_tiles for k = 0 .. n_groups-1, i.e. one run each of n_groups
+     * tiles spread over the frame, and every LANE walks through them on its own: pixel `lane` of the first tile for
+     * run 0, then pixel `lane` of the next tile for run 1, without waiting for the other lanes.  A wave therefore
+     * ends when its slowest lane has done several pixels' worth of work, not when the slowest pixel of one tile is
+     * done: tiles that straddle the light or a silhouette hold pixels whose paths differ severalfold in length.
+     * For each k the map B -> tile is a bijection, so every (tile, run) is rendered exactly once.  With more than one
+     * run the per-pixel sums go to `partial`, one frame per run, and combine_kernel adds them to accum in run order. */
     extern __shared__ int stack_mem[];                 /* RT_BLOCK ints, then RT_F_BVH: stack_depth x RT_BLOCK */
     int* slots = stack_mem + (threadIdx.x & ~63u);     /* 64 ints per wave for the wave-wide ball draw */
     int* stack = stack_mem + RT_BLOCK + ((F & RT_F_BVH) ? threadIdx.x : 0);
     /* the grid tiles the window win = (x0, y0, width, height) of the W x H frame; pixel coordinates and the
      * pixel index (RNG address, accum row) are the frame's, so a window renders what the full frame would */
-    int i, j;
-    tile_pixel(win.z, xcd_tile(blockIdx.x, gridDim.x), threadIdx.x, i, j);
-    const bool valid = i < win.z && j < win.w;
-    i += win.x; j += win.y;
-    const uint32_t pixel = (uint32_t)(j * W + i);
+    uint32_t k = 0;                                    /* the run this lane is on */
+    uint32_t s;
+    PathRng g;
+    rng_start(g, k0, k1, 0u, 0u);                      /* g.pixel = the pixel's index in the frame, ~0u outside the window */
+    /* depth 0: colour()'s loop body never runs and every sample is black (main.cu:53,71) */
+#define RT_RUN_END(k_) (s_last - s_first - (k_) * per_group < per_group ? s_last : s_first + ((k_) + 1u) * per_group)
+#define RT_ENTER_RUN                                                                                      \
+    {                                                                                                     \
+        int i_, j_;                                                                                       \
+        tile_pixel(win.z, (int)((blockIdx.x + k * tile_step) % gridDim.x), threadIdx.x, i_, j_);          \
+        const bool valid_ = i_ < win.z && j_ < win.w;                                                     \
+        g.pixel = valid_ ? (uint32_t)((j_ + win.y) * W + i_ + win.x) : 0xffffffffu;                       \
+        s = (valid_ && max_depth > 0) ? s_first + k * per_group : RT_RUN_END(k);                          \
+    }
+#define RT_FLUSH_RUN                                                                                      \
+    if (g.pixel != 0xffffffffu) {                                                                         \
+        if (partial) {                                                                                    \
+            float* a_ = partial + 3 * ((size_t)k * (size_t)W * (size_t)H + (size_t)g.pixel);              \
+            a_[0] = sum.x; a_[1] = sum.y; a_[2] = sum.z;                                                  \
+        } else {                                                                                          \
+            float* a_ = accum + 3 * (size_t)g.pixel;                                                      \
+            a_[0] += sum.x; a_[1] += sum.y; a_[2] += sum.z;                                               \
+        }                                                                                                 \
+    }
+    RT_ENTER_RUN
 
     V3 sum = mk(0.f, 0.f, 0.f);
-    /* depth 0: colour()'s loop body never runs and every sample is black (main.cu:53,71) */
-    uint32_t s = (valid && max_depth > 0) ? s_begin : s_end;
     bool alive = false;
     DRay ray = {mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f), 0.f};
     V3 att = mk(1.f, 1.f, 1.f), emi = mk(0.f, 0.f, 0.f);
     int depth = 0;
     uint32_t n_rays = 0;
-    PathRng g;
-    rng_start(g, k0, k1, pixel, 0u);
 
     RT_STAMP_DECL
     while (true) {
         RT_STAMP(5)
-        if (!alive && s < s_end) {
+        if (!alive && s >= RT_RUN_END(k) && k + 1 < n_groups) {
+            /* this lane's run is done: hand in its sum and go on to the lane's pixel in the block's next tile */
+            RT_FLUSH_RUN
+            ++k;
+            RT_ENTER_RUN
+            sum = mk(0.f, 0.f, 0.f);
+        }
+        if (!alive && s < RT_RUN_END(k)) {
             /* main.cu:185-188: jittered pixel position, camera ray, fresh path */
-            rng_start(g, k0, k1, pixel, s);
+            g.sample = s;
             rt_u32x4 cw = rng_block(g, RT_RNG_CAMERA, 0u, 0u);
-            float u = float(i + rt_u32_to_uniform(cw.x)) / float(W);
-            float v = float(j + rt_u32_to_uniform(cw.y)) / float(H);
+            const uint32_t j = g.pixel / (uint32_t)W, i = g.pixel - j * (uint32_t)W;
+            float u = float((int)i + rt_u32_to_uniform(cw.x)) / float(W);
+            float v = float((int)j + rt_u32_to_uniform(cw.y)) / float(H);
             ray = generate_ray<F>(S.cam, u, v, rt_u32_to_uniform(cw.z), g);
             att = mk(1.f, 1.f, 1.f);
             emi = mk(0.f, 0.f, 0.f);
@@ -176,7 +213,7 @@ __global__ __launch_bounds__(RT_BLOCK, rt_render_waves(F)) void render_kernel(DS
             ++s;
         }
         RT_STAMP(0)
-        if (__ballot(alive) == 0ull) break;
+        if (__ballot(alive || k + 1 < n_groups) == 0ull) break;
         /* one iteration of colour() / colourUnlit(), main.cu:53-70 / :77-98, for every live lane.  The
          * body is kept flat (flags, not nested branches) because the unit-ball draw in the middle is
          * made by all 64 lanes together. */
@@ -238,12 +275,12 @@ __global__ __launch_bounds__(RT_BLOCK, rt_render_waves(F)) void render_kernel(DS
     }
     RT_STAMP(4)
     RT_STAMP_FLUSH
-    if (valid) {
-        float* a = accum + 3 * (size_t)pixel;
-        a[0] += sum.x; a[1] += sum.y; a[2] += sum.z;
-    }
-    /* ray / sample counters: one atomic per wave */
-    unsigned long long r = n_rays, p = valid ? (unsigned long long)(s_end - s_begin) : 0ull;
+    RT_FLUSH_RUN
+#undef RT_FLUSH_RUN
+#undef RT_ENTER_RUN
+#undef RT_RUN_END
+    /* ray / sample counters: one atomic per wave; every sample of the window is rendered (black when max_depth is 0) */
+    unsigned long long r = n_rays, p = (blockIdx.x == 0 && threadIdx.x == 0) ? (unsigned long long)win.z * win.w * (s_last - s_first) : 0ull;
     for (int off = 32; off > 0; off >>= 1) {
         r += __shfl_down(r, off);
         p += __shfl_down(p, off);
@@ -252,6 +289,18 @@ __global__ __launch_bounds__(RT_BLOCK, rt_render_waves(F)) void render_kernel(DS
         atomicAdd(&counters[0], r);
         atomicAdd(&counters[1], p);
     }
+}
+
+/* accum[window] += partial[0] + partial[1] + ... : the sample groups of render_kernel, in group order */
+__global__ __launch_bounds__(RT_BLOCK) void combine_kernel(float* __restrict__ accum, const float* __restrict__ partial, int W, int H, int4 win, int groups)
+{
+    const size_t i = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x;         /* float index inside the window */
+    const size_t row = (size_t)win.z * 3;
+    if (i >= row * (size_t)win.w) return;
+    const size_t at = ((size_t)(win.y + (int)(i / row)) * (size_t)W + (size_t)win.x) * 3 + i % row;
+    float v = accum[at];
+    for (int g = 0; g < groups; ++g) v += partial[(size_t)g * (size_t)W * (size_t)H * 3 + at];
+    accum[at] = v;
 }
 
 __global__ __launch_bounds__(RT_BLOCK) void resolve_kernel(const float* __restrict__ accum, size_t n, float inv_spp,
@@ -293,6 +342,7 @@ struct rt_ctx {
     DScene ds;
     void* d_objs = nullptr;  void* d_ops = nullptr;   void* d_mats = nullptr; void* d_texs = nullptr;
     void* d_image = nullptr; void* d_nodes = nullptr; void* d_leafs = nullptr; void* d_prog = nullptr; void* d_nodes4 = nullptr;
+    float* d_partial = nullptr; size_t partial_floats = 0;    /* per-group frames of the megakernel's sample groups */
     void* d_prog_wf = nullptr; void* d_wf_groups = nullptr;   /* the world list in the wavefront integrator's form */
     int n_wf_groups = 0, n_wf_plain = 0;
     unsigned long long* d_counters = nullptr;
@@ -344,6 +394,7 @@ extern "C" void rt_ctx_destroy(rt_ctx* c)
     free_scene(c);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->wf_mem) (void)hipFree(c->wf_mem);
+    if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->wf_host_count) (void)hipHostFree(c->wf_host_count);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -631,11 +682,38 @@ extern "C" int rt_render_accumulate_window(rt_ctx* c, int w, int h, int x0, int 
         return wrc ? wrc : nrc;
     }
     const size_t lds = RT_BLOCK * sizeof(int) + stack_bytes(c);
+    /* Runs.  The sample range is cut into up to 16 runs of >= 64 samples, and a block renders one run each of as many
+     * tiles spread over the frame, its lanes walking through them independently (render_kernel).  Measured on the
+     * Cornell box, 1024 x 1024 x 1024 spp: 1 run (a wave stays on one tile until its slowest pixel is done) 20.9 Grays/s
+     * before this and 19.2 with the walking code in the loop; 4 runs 20.5, 8 runs 23.6, 16 runs 24.5, 32-128 runs 24.5.
+     * The number of runs depends on the sample count only, so a window and the full frame group a pixel's samples
+     * alike; calls of fewer than 128 samples have one run and sum a pixel's samples in order. */
+    const uint32_t n_samples = s1 - s0;
+    uint32_t groups = n_samples / 64u;
+    groups = groups < 1u ? 1u : (groups > 16u ? 16u : groups);
+    if (const char* e = std::getenv("RT_MEGA_GROUPS")) { groups = (uint32_t)std::atoi(e); if (groups < 1 || groups > n_samples) groups = 1; }
+    const uint32_t per_group = (n_samples + groups - 1) / groups;
+    groups = (n_samples + per_group - 1) / per_group;
+    float* partial = nullptr;
+    if (groups > 1) {
+        const size_t need = (size_t)groups * (size_t)w * (size_t)h * 3;
+        if (need > c->partial_floats) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (c->d_partial) { (void)hipFree(c->d_partial); c->d_partial = nullptr; c->partial_floats = 0; }
+            if (hipMalloc((void**)&c->d_partial, need * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); groups = 1; }
+            else c->partial_floats = need;
+        }
+        partial = groups > 1 ? c->d_partial : nullptr;
+    }
+    const uint32_t per = groups > 1 ? per_group : n_samples;
+    /* block B takes run k of tile (B + k * tile_step) mod n_tiles: steps of about 0.38 of the frame */
+    uint32_t tile_step = (uint32_t)(grid.x * 0.3819660113);
+    if (tile_step == 0) tile_step = 1;
     /* the smallest compiled feature set that covers the scene */
     static const uint32_t variants[] = {RT_V_PLANAR, RT_V_PLANAR_MEDIA, RT_V_LIST, RT_V_BVH_TRI, RT_F_ALL, RT_V_NOISE};
     uint32_t pick = RT_V_NOISE;
     for (uint32_t v : variants) if ((c->features & ~v) == 0) { pick = v; break; }
-#define RT_LAUNCH(V, G) render_kernel<V, G><<<grid, RT_BLOCK, lds, c->stream>>>(c->ds, w, h, win, s0, s1, k0, k1, max_depth, accum, c->d_counters)
+#define RT_LAUNCH(V, G) render_kernel<V, G><<<grid, RT_BLOCK, lds, c->stream>>>(c->ds, w, h, win, s0, s1, k0, k1, max_depth, accum, c->d_counters, per, partial, groups, tile_step)
 #define RT_LAUNCH_BG(V) { if (background == RT_BG_BLACK) RT_LAUNCH(V, RT_BG_BLACK); else RT_LAUNCH(V, RT_BG_SKY); }
     switch (pick) {
     case RT_V_PLANAR:       RT_LAUNCH_BG(RT_V_PLANAR) break;
@@ -648,6 +726,11 @@ extern "C" int rt_render_accumulate_window(rt_ctx* c, int w, int h, int x0, int 
 #undef RT_LAUNCH_BG
 #undef RT_LAUNCH
     hipError_t le = hipGetLastError();
+    if (le == hipSuccess && partial) {
+        const size_t n_win = (size_t)win.z * win.w * 3;
+        combine_kernel<<<dim3((unsigned)((n_win + RT_BLOCK - 1) / RT_BLOCK)), RT_BLOCK, 0, c->stream>>>(accum, partial, w, h, win, (int)groups);
+        le = hipGetLastError();
+    }
     HIPCHK(hipEventRecord(e1, c->stream));
     int nrc = note_render(c, e0, e1);
     if (le != hipSuccess) { rt_set_error(std::string("render launch failed: ") + hipGetErrorString(le)); return RT_ERR_HIP; }
