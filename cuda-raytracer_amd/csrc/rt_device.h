@@ -515,13 +515,20 @@ __device__ __forceinline__ void generic_closest(const DScene& S, int oi, const D
 
 /* one 32-byte scan record, fetched through the scalar cache */
 struct ProgRec { uint32_t head; int32_t obj; float v0, v1, v2, v3, v4, v5; };
+/* The record is read through the constant address space: the program is never written while a kernel runs, and
+ * a load from a wave-uniform constant address is a scalar load (s_load_dwordx8) whatever else the kernel stores.
+ * Read as ordinary global memory it stops being one as soon as the loop around it holds a store the compiler
+ * cannot tell apart from the program (the per-run flush of render_kernel, the hit write of wf_intersect): the
+ * records then come through 64 identical vector loads and every test on them runs on the VALU. */
+typedef uint32_t rt_u32x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ ProgRec prog_load(const DProg* p)
 {
-    const uint4 a = reinterpret_cast<const uint4*>(p)[0], b = reinterpret_cast<const uint4*>(p)[1];
+    typedef const __attribute__((address_space(4))) rt_u32x8_t* const_rec_ptr;
+    const rt_u32x8_t w = *(const_rec_ptr)(uintptr_t)p;
     ProgRec r;
-    r.head = a.x; r.obj = (int32_t)a.y;
-    r.v0 = __uint_as_float(a.z); r.v1 = __uint_as_float(a.w);
-    r.v2 = __uint_as_float(b.x); r.v3 = __uint_as_float(b.y); r.v4 = __uint_as_float(b.z); r.v5 = __uint_as_float(b.w);
+    r.head = w[0]; r.obj = (int32_t)w[1];
+    r.v0 = __uint_as_float(w[2]); r.v1 = __uint_as_float(w[3]);
+    r.v2 = __uint_as_float(w[4]); r.v3 = __uint_as_float(w[5]); r.v4 = __uint_as_float(w[6]); r.v5 = __uint_as_float(w[7]);
     return r;
 }
 

@@ -3,10 +3,11 @@
  *
  * render_kernel replaces the reference's `render` (main.cu:125-198).  The reference runs one
  * thread per pixel and lets a 32-lane warp wait for its slowest lane through numSamples x <=100
- * bounces.  Here a 64-lane wave owns an 8x8 pixel tile and every lane is a small state machine:
- * the moment its path ends it starts its pixel's next sample, so the wave's closest-hit step
- * always runs with (almost) all lanes live, and the per-pixel sum stays in registers until the
- * lane has finished its sample range — no queues in HBM, no atomics, a fixed summation order.
+ * bounces.  Here every lane of a 64-lane wave is a small state machine: the moment its path ends it
+ * starts its pixel's next sample, and when a run of samples of that pixel is done it moves on to its
+ * pixel in the block's next tile, so the wave's closest-hit step runs with (almost) all lanes live to
+ * the end; a run's sum stays in registers until the run is finished — no queues in HBM, no atomics,
+ * a fixed summation order.
  * For scenes whose tables sit in the scalar cache (Cornell: 9 objects) the kernel is bound by
  * VALU issue; DESIGN.md has the numbers and why a queue-based wavefront would instead be bound
  * by its own queue traffic there.
