@@ -343,12 +343,26 @@ __device__ __forceinline__ bool leaf_t(const DScene& S, const DObj& o, DRay r, f
     return prim_t<F>(obj_type(o.head), o.f, r, tMin, tMax, t, aux);
 }
 
+/* A row of the object table read through the constant address space (see prog_load): where the index is the
+ * same for the whole wave — the objects of the world list, a group's children, a medium's boundary — the row
+ * arrives by scalar loads and lives in SGPRs; a lane-dependent index still works (vector loads). */
+__device__ __forceinline__ DObj obj_const(const DObj* p)
+{
+    typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+    typedef const __attribute__((address_space(4))) u32x16* const_half_ptr;
+    static_assert(sizeof(DObj) == 2 * sizeof(u32x16), "DObj is two 64-byte halves");
+    const u32x16 w[2] = {((const_half_ptr)(uintptr_t)p)[0], ((const_half_ptr)(uintptr_t)p)[1]};
+    DObj o;
+    __builtin_memcpy(&o, w, sizeof o);
+    return o;
+}
+
 /* ConstantMedium::hit Volumes.cuh:26-49 (ray already in the medium's frame) */
 template <uint32_t F>
 __device__ __forceinline__ bool medium_t(const DScene& S, const DObj& o, const DRay& r, float tMin, float tMax,
                                          const PathRng& g, uint32_t bounce, float& t_out)
 {
-    const DObj& b = S.objs[o.child_begin];
+    const DObj b = obj_const(S.objs + o.child_begin);
     float t1, t2;
     int unused;
     if ((F & RT_F_PLANAR) && obj_type(b.head) == RT_OBJ_BOX) {
@@ -483,7 +497,7 @@ __device__ __forceinline__ void group_closest(const DScene& S, int gi, const DOb
     if (!(F & RT_F_GROUPLIST) && gi >= 0) return;
     for (int i = 0; i < g.child_count; ++i) {
         int oi = g.child_begin + i;
-        const DObj& o = S.objs[oi];
+        const DObj o = obj_const(S.objs + oi);
         float t; int aux;
         if ((F & RT_F_MEDIA) && obj_type(o.head) == RT_OBJ_MEDIUM) {
             if (rng) {
@@ -499,7 +513,7 @@ template <uint32_t F>
 __device__ __forceinline__ void generic_closest(const DScene& S, int oi, const DRay& r, float tMin, HitLite& best,
                                                 const PathRng* rng, uint32_t bounce, int* stack)
 {
-    const DObj& o = S.objs[oi];
+    const DObj o = obj_const(S.objs + oi);
     const int ty = obj_type(o.head);
     float t; int aux;
     if (ty == RT_OBJ_GROUP) {
