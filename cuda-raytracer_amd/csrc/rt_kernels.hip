@@ -692,6 +692,7 @@ extern "C" int rt_render_accumulate_window(rt_ctx* c, int w, int h, int x0, int 
     const uint32_t n_samples = s1 - s0;
     uint32_t groups = n_samples / 64u;
     groups = groups < 1u ? 1u : (groups > 16u ? 16u : groups);
+    /* RT_MEGA_GROUPS in the environment overrides the number of runs (how the figures above were measured) */
     if (const char* e = std::getenv("RT_MEGA_GROUPS")) { groups = (uint32_t)std::atoi(e); if (groups < 1 || groups > n_samples) groups = 1; }
     const uint32_t per_group = (n_samples + groups - 1) / groups;
     groups = (n_samples + per_group - 1) / per_group;
