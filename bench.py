@@ -147,7 +147,6 @@ def main():
         ctx = b.Context(local_rank, stream.cuda_stream)
         ctx.upload(scene)
         ctx.set_integrator({"auto": 0, "megakernel": 1, "wavefront": 2}[args.integrator])
-        wavefront = args.integrator == "wavefront" or (args.integrator == "auto" and flat.n_bvh_items >= 65536)
         accum = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
         rgb = None
 
@@ -177,6 +176,7 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         c = ctx.counters()
+        wavefront = c.last_integrator == 2            # the form the library ran (rt_counters.last_integrator)
 
         tot = torch.tensor([float(c.rays), float(c.samples)], dtype=torch.float64, device=dev)
         tmax = torch.tensor([dt, c.render_ms / max(1, c.render_launches)], dtype=torch.float64, device=dev)

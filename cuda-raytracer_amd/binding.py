@@ -66,7 +66,7 @@ class RtHitRecord(C.Structure):
 
 class RtCounters(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("render_ms", C.c_double),
-                ("last_render_ms", C.c_double), ("render_launches", C.c_uint32), ("pad", C.c_uint32)]
+                ("last_render_ms", C.c_double), ("render_launches", C.c_uint32), ("last_integrator", C.c_uint32)]
 
 
 # numpy dtype with the layout of rt_hit_record / rto_hit (52 bytes)

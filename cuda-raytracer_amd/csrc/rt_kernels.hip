@@ -332,6 +332,7 @@ struct rt_ctx {
     int n_bvh_items = 0;
     uint32_t features = 0;    /* RT_F_* of the uploaded scene */
     int integrator = RT_INTEGRATOR_AUTO;
+    int last_integrator = 0;          /* form the latest render call ran in (rt_counters) */
     /* wavefront path state (rt_wavefront.h), allocated on first use and kept */
     WfState wf = {};
     void* wf_mem = nullptr;
@@ -674,6 +675,7 @@ extern "C" int rt_render_accumulate_window(rt_ctx* c, int w, int h, int x0, int 
      * 1000-sphere cluster 2.18; 488 spheres in a world BVH 1.59; 16 boxes 0.62; no BVH at all (Cornell) 0.30. */
     const bool big = c->n_bvh_items >= RT_WF_AUTO_ITEMS;
     const bool wavefront = c->integrator == RT_INTEGRATOR_WAVEFRONT || (c->integrator == RT_INTEGRATOR_AUTO && big && c->stack4 <= WF_LDS_STACK + WF_OVF_STACK);
+    c->last_integrator = wavefront ? RT_INTEGRATOR_WAVEFRONT : RT_INTEGRATOR_MEGAKERNEL;
     if (wavefront) {
         int wrc = (c->features & ~RT_V_BVH_TRI) == 0 ? wf_run<RT_V_BVH_TRI>(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum)
                   : (c->features & RT_F_NOISE)       ? wf_run<RT_V_NOISE>(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum)
@@ -874,7 +876,7 @@ extern "C" int rt_get_counters(rt_ctx* c, rt_counters* out)
     out->render_ms = c->render_ms;
     out->last_render_ms = c->last_ms;
     out->render_launches = c->launches;
-    out->pad = 0;
+    out->last_integrator = (uint32_t)c->last_integrator;
     return RT_OK;
 }
 

@@ -53,7 +53,7 @@ typedef struct rt_counters {
     double   render_ms;       /* HIP-event time of those render kernels, summed */
     double   last_render_ms;  /* HIP-event time of the most recent render kernel */
     uint32_t render_launches;
-    uint32_t pad;
+    uint32_t last_integrator; /* form the most recent render call ran in: RT_INTEGRATOR_MEGAKERNEL or _WAVEFRONT; 0 = none yet */
 } rt_counters;
 
 const char* rt_last_error(void);

@@ -256,7 +256,10 @@ def test_wavefront_at_full_size(binding, gpu_ctx):
     w1 = render_gpu(gpu_ctx, binding, sc, W, H, 0, 1, 9, integrator="wavefront")
     cw = gpu_ctx.counters()
     assert cm.rays == cw.rays
+    assert (cm.last_integrator, cw.last_integrator) == (1, 2)
     assert torch.equal(m, w1)          # one stream per pixel: same summation order, same bits
+    auto = render_gpu(gpu_ctx, binding, sc, W, H, 0, 1, 9, integrator="auto")
+    assert gpu_ctx.counters().last_integrator == 2 and torch.equal(auto, w1)     # a big BVH: auto = wavefront
 
 
 def test_smoke_and_final_at_full_size(binding, gpu_ctx):
@@ -367,6 +370,7 @@ def test_many_renders_between_counter_reads(binding, gpu_ctx):
         gpu_ctx.render_accumulate(acc, W, H, i, i + 1, 419, 100, sc.background)
     c = gpu_ctx.counters()
     assert c.render_launches == calls and c.samples == calls * W * H and c.render_ms > 0
+    assert c.last_integrator == 1                                            # no BVH: auto = megakernel
     gpu_ctx.reset_counters()
     gpu_ctx.render_accumulate(acc, W, H, 0, 1, 419, 100, sc.background)      # ordered after the reset
     c = gpu_ctx.counters()
