@@ -588,13 +588,12 @@ static int wf_run(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t s1, u
     W.n_slots = (uint32_t)n_slots; W.n_pixels = n_pixels; W.streams = streams;
     W.win_x0 = (uint32_t)win.x; W.win_y0 = (uint32_t)win.y; W.win_w = (uint32_t)win.z; W.frame_w = (uint32_t)w;
     W.prog = (const DProg*)c->d_prog_wf; W.groups = (const int*)c->d_wf_groups; W.n_groups = c->n_wf_groups;
-    /* a refill runs the plain records of the world list for the lanes it fills: the longer that list, the more
-     * lanes it should wait for (measured: 1 record -> 32 best, the final scene's 11 -> 48) */
-#ifdef WF_REFILL_SHORT
-    W.refill_min = c->n_wf_plain <= 4 ? WF_REFILL_SHORT : WF_REFILL_LONG;      /* tuning builds */
-#else
-    W.refill_min = c->n_wf_plain <= 4 ? 32 : 48;
-#endif
+    /* a refill runs the plain records of the world list for the lanes it fills, so it waits for a batch of idle
+     * lanes.  Measured at 1080p (tools/refill_sweep.py), Grays/s at 16 / 24 / 32 / 40 / 48 / 56 idle lanes: final scene
+     * (11 plain records) 2.78 / 2.93 / 3.01 / 3.04 / 3.01 / 2.90; 1M triangles (1 record) 2.08 / 2.10 / 2.12 / 2.12 / 2.12 / 2.09 */
+    W.refill_min = 40;
+    /* RT_WF_REFILL in the environment overrides it (how those figures were measured) */
+    if (const char* e = std::getenv("RT_WF_REFILL")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) W.refill_min = v; }
     if (c->stack4 > WF_LDS_STACK + WF_OVF_STACK) { rt_set_error("wavefront integrator: BVH deeper than its traversal stack"); return RT_ERR_UNSUPPORTED; }
     const size_t lds = (size_t)(c->stack4 < WF_LDS_STACK ? c->stack4 : WF_LDS_STACK) * RT_BLOCK * sizeof(int);
     HIPCHK(hipMemsetAsync(W.count, 0, 4 * sizeof(uint32_t), c->stream));
@@ -805,7 +804,7 @@ extern "C" int rt_reduce_accum(rt_ctx* const* ctxs, float* const* accum, int n, 
     int rc = rccl_load();
     if (rc) return rc;
     if (g_rccl.devices != devices) {
-        for (ncclComm_t c : g_rccl.comms) (void)g_rccl.CommDestroy(c);
+        for (ncclComm_t c : g_rccl.comms) if (c) (void)g_rccl.CommDestroy(c);
         g_rccl.comms.assign(n, nullptr);
         g_rccl.devices.clear();
         RCCLCHK(g_rccl.CommInitAll(g_rccl.comms.data(), n, devices.data()));
