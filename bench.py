@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workload line of the default run")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for RCCL; must be set before the first HIP call
     import torch
     import torch.distributed as dist
 
@@ -127,7 +128,6 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
     b = entry.load_binding()

@@ -71,6 +71,8 @@ constexpr int wf_intersect_waves(uint32_t F) { return (F & ~(RT_F_BVH | RT_F_TRI
 #define WF_CHUNK 1024        /* queue entries a wave claims per atomic, at most */
 #define WF_PRIM_BATCH 20     /* lanes at a leaf that make a primitive step worth running */
 #define WF_NODE_LOW 16       /* fewer interior lanes than this: run whatever else is waiting */
+/* a flat optimum: PRIM_BATCH 16 / 24 and NODE_LOW 8 / 24 are all within 0.5 % of these on the 1M-triangle and final
+ * scenes (tools/lib_sweep.py) */
 #endif
 
 /* ------------------------------------------------------------------ intersect -- */
