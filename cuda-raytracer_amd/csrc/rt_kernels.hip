@@ -34,6 +34,7 @@
 #define RT_V_LIST         (RT_F_ALL & ~RT_F_BVH)                                       /* any scene without a BVH */
 #define RT_V_BVH_TRI      (RT_F_BVH | RT_F_TRI | RT_F_PLANAR)                          /* triangle mesh + area light */
 #define RT_V_NOISE        (RT_F_ALL | RT_F_NOISE)                                      /* anything with a NoiseTexture */
+#define RT_V_NOTRI        (RT_F_ALL & ~(RT_F_TRI | RT_F_GROUPLIST))                    /* wavefront form: the final scene */
 #ifndef RT_WF_AUTO_ITEMS
 #define RT_WF_AUTO_ITEMS 128          /* BVH items from which RT_INTEGRATOR_AUTO takes the wavefront form */
 #endif
@@ -676,9 +677,11 @@ extern "C" int rt_render_accumulate_window(rt_ctx* c, int w, int h, int x0, int 
     const bool wavefront = c->integrator == RT_INTEGRATOR_WAVEFRONT || (c->integrator == RT_INTEGRATOR_AUTO && big && c->stack4 <= WF_LDS_STACK + WF_OVF_STACK);
     c->last_integrator = wavefront ? RT_INTEGRATOR_WAVEFRONT : RT_INTEGRATOR_MEGAKERNEL;
     if (wavefront) {
+        /* the first variant that covers the scene's features */
         int wrc = (c->features & ~RT_V_BVH_TRI) == 0 ? wf_run<RT_V_BVH_TRI>(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum)
-                  : (c->features & RT_F_NOISE)       ? wf_run<RT_V_NOISE>(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum)
-                                                     : wf_run<RT_F_ALL>(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum);
+                  : (c->features & ~RT_V_NOTRI) == 0 ? wf_run<RT_V_NOTRI>(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum)
+                  : (c->features & ~RT_F_ALL) == 0   ? wf_run<RT_F_ALL>(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum)
+                                                     : wf_run<RT_V_NOISE>(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum);
         HIPCHK(hipEventRecord(e1, c->stream));
         int nrc = note_render(c, e0, e1);
         return wrc ? wrc : nrc;

@@ -64,7 +64,10 @@ __device__ __forceinline__ uint32_t wf_frame_pixel(const WfState& W, uint32_t sl
 enum { WF_NEED = 0, WF_BVH = 2 };
 /* waves per SIMD the intersect kernel is compiled for: the triangle-mesh variant fits 96 VGPRs without spilling
  * (5 waves: +1.5 % on the 1M-triangle scene); the general one spills at 5 (final scene -27 %) */
-constexpr int wf_intersect_waves(uint32_t F) { return (F & ~(RT_F_BVH | RT_F_TRI | RT_F_PLANAR)) == 0 ? 5 : 4; }
+#ifndef WF_GENERAL_WAVES
+#define WF_GENERAL_WAVES 4
+#endif
+constexpr int wf_intersect_waves(uint32_t F) { return (F & ~(RT_F_BVH | RT_F_TRI | RT_F_PLANAR)) == 0 ? 5 : WF_GENERAL_WAVES; }
 #define WF_LDS_STACK 20      /* traversal-stack entries per lane kept in LDS; deeper ones go to scratch */
 #define WF_OVF_STACK 44      /* entries of the scratch overflow: 3 per level of a 4-wide tree, rarely reached */
 #ifndef WF_PRIM_BATCH
