@@ -77,7 +77,7 @@ EXPORTS = [
     "rt_last_error", "rt_scene_create_builtin", "rt_scene_from_flat", "rt_scene_flat",
     "rt_scene_default_background", "rt_scene_destroy", "rt_ctx_create", "rt_ctx_destroy",
     "rt_scene_upload", "rt_trace_rays", "rt_trace_primary", "rt_render_accumulate", "rt_render_accumulate_window", "rt_resolve",
-    "rt_ctx_set_integrator", "rt_reduce_accum", "rt_synchronize", "rt_get_counters", "rt_reset_counters", "rt_quantise_rgb8", "rt_write_ppm", "rt_write_png", "rt_read_ppm", "rt_free_pixels", "rt_flat_features", "rt_flat_program", "rt_flat_program_split", "rt_flat_bvh_stats",
+    "rt_ctx_set_integrator", "rt_reduce_accum", "rt_reduce_scatter_rows", "rt_synchronize", "rt_get_counters", "rt_reset_counters", "rt_quantise_rgb8", "rt_write_ppm", "rt_write_png", "rt_read_ppm", "rt_free_pixels", "rt_flat_features", "rt_flat_program", "rt_flat_program_split", "rt_flat_bvh_stats",
 ]
 
 
@@ -109,6 +109,7 @@ def load_library(path=LIB_PATH):
     lib.rt_resolve.argtypes = [vp, vp, i32, i32, u32, i32, vp]
     lib.rt_ctx_set_integrator.argtypes = [vp, i32]
     lib.rt_reduce_accum.argtypes = [C.POINTER(vp), C.POINTER(vp), i32, u64, i32]
+    lib.rt_reduce_scatter_rows.argtypes = [C.POINTER(vp), C.POINTER(vp), i32, i32, i32, C.POINTER(i32)]
     lib.rt_synchronize.argtypes = [vp]
     lib.rt_get_counters.argtypes = [vp, C.POINTER(RtCounters)]
     lib.rt_reset_counters.argtypes = [vp]

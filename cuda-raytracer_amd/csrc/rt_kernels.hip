@@ -793,17 +793,17 @@ int rccl_load()
     rt_set_error(std::string(#call) + ": " + g_rccl.GetErrorString(r_)); return RT_ERR_RCCL; } } while (0)
 }  // namespace
 
-extern "C" int rt_reduce_accum(rt_ctx* const* ctxs, float* const* accum, int n, uint64_t count, int root)
+/* checks the lists and returns the cached communicators for exactly this device list (made on first use) */
+static int rccl_comms(const char* who, rt_ctx* const* ctxs, float* const* accum, int n, std::vector<int>& devices)
 {
-    if (!ctxs || !accum || n < 1 || root < 0 || root >= n || count == 0) { rt_set_error("rt_reduce_accum: bad arguments"); return RT_ERR_ARG; }
-    std::vector<int> devices(n);
+    if (!ctxs || !accum || n < 1) { rt_set_error(std::string(who) + ": bad arguments"); return RT_ERR_ARG; }
+    devices.resize(n);
     for (int i = 0; i < n; ++i) {
-        if (!ctxs[i] || !accum[i]) { rt_set_error("rt_reduce_accum: null context or buffer"); return RT_ERR_ARG; }
+        if (!ctxs[i] || !accum[i]) { rt_set_error(std::string(who) + ": null context or buffer"); return RT_ERR_ARG; }
         devices[i] = ctxs[i]->device;
         for (int j = 0; j < i; ++j)
-            if (devices[j] == devices[i]) { rt_set_error("rt_reduce_accum: two contexts on one device"); return RT_ERR_ARG; }
+            if (devices[j] == devices[i]) { rt_set_error(std::string(who) + ": two contexts on one device"); return RT_ERR_ARG; }
     }
-    std::lock_guard<std::mutex> lock(g_rccl_mutex);
     int rc = rccl_load();
     if (rc) return rc;
     if (g_rccl.devices != devices) {
@@ -813,12 +813,46 @@ extern "C" int rt_reduce_accum(rt_ctx* const* ctxs, float* const* accum, int n, 
         RCCLCHK(g_rccl.CommInitAll(g_rccl.comms.data(), n, devices.data()));
         g_rccl.devices = devices;
     }
+    return RT_OK;
+}
+
+extern "C" int rt_reduce_accum(rt_ctx* const* ctxs, float* const* accum, int n, uint64_t count, int root)
+{
+    if (n < 1 || root < 0 || root >= n || count == 0) { rt_set_error("rt_reduce_accum: bad arguments"); return RT_ERR_ARG; }
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    std::vector<int> devices;
+    int rc = rccl_comms("rt_reduce_accum", ctxs, accum, n, devices);
+    if (rc) return rc;
     /* rank i = position i in the lists; in place: the root's buffer receives the sum */
     RCCLCHK(g_rccl.GroupStart());
     for (int i = 0; i < n; ++i) {
         HIPCHK(hipSetDevice(devices[i]));
         ncclResult_t r = g_rccl.Reduce(accum[i], accum[i], (size_t)count, ncclFloat, ncclSum, root, g_rccl.comms[i], ctxs[i]->stream);
         if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); rt_set_error(std::string("ncclReduce: ") + g_rccl.GetErrorString(r)); return RT_ERR_RCCL; }
+    }
+    RCCLCHK(g_rccl.GroupEnd());
+    return RT_OK;
+}
+
+extern "C" int rt_reduce_scatter_rows(rt_ctx* const* ctxs, float* const* accum, int n, int w, int h, int* rows)
+{
+    if (n < 1 || !frame_ok(w, h) || !rows) { rt_set_error("rt_reduce_scatter_rows: bad arguments"); return RT_ERR_ARG; }
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    std::vector<int> devices;
+    int rc = rccl_comms("rt_reduce_scatter_rows", ctxs, accum, n, devices);
+    if (rc) return rc;
+    for (int i = 0; i <= n; ++i) rows[i] = (int)((long long)h * i / n);
+    /* one reduce per band, rooted at the band's owner, all in one group: every GPU receives 1/n of the frame
+     * instead of GPU 0 receiving all of it (bands may differ in height, which ncclReduceScatter cannot express) */
+    RCCLCHK(g_rccl.GroupStart());
+    for (int band = 0; band < n; ++band) {
+        const size_t off = (size_t)rows[band] * w * 3, cnt = (size_t)(rows[band + 1] - rows[band]) * w * 3;
+        if (cnt == 0) continue;
+        for (int i = 0; i < n; ++i) {
+            HIPCHK(hipSetDevice(devices[i]));
+            ncclResult_t r = g_rccl.Reduce(accum[i] + off, accum[i] + off, cnt, ncclFloat, ncclSum, band, g_rccl.comms[i], ctxs[i]->stream);
+            if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); rt_set_error(std::string("ncclReduce: ") + g_rccl.GetErrorString(r)); return RT_ERR_RCCL; }
+        }
     }
     RCCLCHK(g_rccl.GroupEnd());
     return RT_OK;

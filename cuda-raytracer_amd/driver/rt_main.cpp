@@ -22,6 +22,7 @@
  * Optional argv: a built-in scene name (default "cornell" = the reference's active scene, main.cu:533;
  * "user" = the scene function in this file) and a scene parameter; and, with no counterpart in the reference
  * (progressive rendering):
+ *   --scatter          leave the sum distributed: every GPU receives and hands back one row band (rt_reduce_scatter_rows)
  *   --tiles            with N GPUs, split the IMAGE into N column bands (the reference's own split, main.cu:128-174,
  *                      generalised from two halves) instead of splitting the samples; the reduce then acts as the stitch
  *   --chunk N          render N samples per call instead of all at once
@@ -84,6 +85,7 @@ static int g_param = 0;
 static int g_shards = 1;
 static int g_chunk = 0, g_stop_at = 0;
 static bool g_tiles = false;
+static bool g_scatter = false;
 static std::string g_checkpoint, g_resume;
 
 /* checkpoint file: this header, then width*height*3 float sums (row 0 = bottom) */
@@ -217,6 +219,7 @@ int main(int argc, char** argv)
         const std::string arg = argv[a];
         const bool has_value = a + 1 < argc;
         if (arg == "--tiles") g_tiles = true;
+        else if (arg == "--scatter") g_scatter = true;
         else if (arg == "--chunk" && has_value) g_chunk = std::atoi(argv[++a]);
         else if (arg == "--stop-at" && has_value) g_stop_at = std::atoi(argv[++a]);
         else if (arg == "--checkpoint" && has_value) g_checkpoint = argv[++a];
@@ -260,16 +263,27 @@ int main(int argc, char** argv)
     std::vector<Shard> shards;
     for (auto& j : jobs) shards.push_back(j.get());
     const size_t n = (size_t)width * height * 3;
-    if (numGPUs > 1) {                                                         /* RCCL reduce over xGMI onto GPU 0 */
-        std::vector<rt_ctx*> ctxs;
-        std::vector<float*> bufs;
-        for (Shard& sh : shards) { ctxs.push_back(sh.ctx); bufs.push_back(sh.accum); }
-        checkRt(rt_reduce_accum(ctxs.data(), bufs.data(), numGPUs, n, 0));
-        for (Shard& sh : shards) checkRt(rt_synchronize(sh.ctx));
-    }
+    std::vector<rt_ctx*> ctxs;
+    std::vector<float*> bufs;
+    for (Shard& sh : shards) { ctxs.push_back(sh.ctx); bufs.push_back(sh.accum); }
     std::vector<float> sum(n);
-    checkHip(hipSetDevice(0));
-    checkHip(hipMemcpy(sum.data(), shards[0].accum, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (g_scatter) {                                                           /* every GPU ends with the total of its row band */
+        std::vector<int> rows((size_t)numGPUs + 1);
+        checkRt(rt_reduce_scatter_rows(ctxs.data(), bufs.data(), numGPUs, width, height, rows.data()));
+        for (int g = 0; g < numGPUs; ++g) {
+            checkRt(rt_synchronize(shards[g].ctx));
+            const size_t off = (size_t)rows[g] * width * 3, cnt = (size_t)(rows[g + 1] - rows[g]) * width * 3;
+            checkHip(hipSetDevice(g));
+            if (cnt) checkHip(hipMemcpy(sum.data() + off, shards[g].accum + off, cnt * sizeof(float), hipMemcpyDeviceToHost));
+        }
+    } else {
+        if (numGPUs > 1) {                                                     /* RCCL reduce over xGMI onto GPU 0 */
+            checkRt(rt_reduce_accum(ctxs.data(), bufs.data(), numGPUs, n, 0));
+            for (Shard& sh : shards) checkRt(rt_synchronize(sh.ctx));
+        }
+        checkHip(hipSetDevice(0));
+        checkHip(hipMemcpy(sum.data(), shards[0].accum, n * sizeof(float), hipMemcpyDeviceToHost));
+    }
     for (size_t g = 0; g < shards.size(); ++g) {
         checkHip(hipSetDevice((int)g));
         checkHip(hipFree(shards[g].accum));

@@ -131,6 +131,12 @@ int  rt_resolve(rt_ctx* c, const float* accum_dev, int width, int height, uint32
  * on the first call, not when this library is loaded; communicators are kept for the next call over the same
  * devices.  One process per GPU (bench.py) does the same through torch.distributed instead. */
 int  rt_reduce_accum(rt_ctx* const* ctxs, float* const* accum_dev, int n, uint64_t count, int root);
+/* The same sum, left distributed (the reference gathers its two halves on the host,
+ * main.cu:711-730): the frame's rows are cut into n bands, rows_out[i]..rows_out[i+1] for context i (rows_out has
+ * n + 1 entries; row 0 is the bottom row, as in accum), and context i's buffer receives the total of ITS band, in
+ * place; the rest of its buffer keeps its own partial sums.  Every GPU then resolves and reads back 1/n of the
+ * frame instead of GPU 0 all of it.  One ncclReduce per band, rooted at the band's owner, all in one group. */
+int  rt_reduce_scatter_rows(rt_ctx* const* ctxs, float* const* accum_dev, int n, int width, int height, int* rows_out);
 int  rt_synchronize(rt_ctx* c);
 int  rt_get_counters(rt_ctx* c, rt_counters* out);   /* synchronizes first */
 int  rt_reset_counters(rt_ctx* c);

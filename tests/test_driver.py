@@ -103,3 +103,9 @@ def test_checkpoint_and_resume(tmp_path):
     r = run_driver(tiles, stdin, "cornell_smoke", "--chunk", "2", "--tiles")
     assert r.returncode == 0 and "columns [0,48)" in r.stderr, r.stderr
     assert np.array_equal(read_ppm(tiles / "output" / "singleGPUTesting.ppm"), a)
+    # the sum left distributed over the GPUs' row bands: with one GPU its band is the whole frame
+    sc = tmp_path / "scatter"
+    sc.mkdir()
+    r = run_driver(sc, stdin, "cornell_smoke", "--chunk", "2", "--scatter")
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(read_ppm(sc / "output" / "singleGPUTesting.ppm"), a)

@@ -43,3 +43,26 @@ def test_single_shard_reduce_and_argument_errors(binding, gpu_ctx):
     assert reduce(lib, [gpu_ctx], [acc], 0, 0) == -1
     assert reduce(lib, [], [], 16, 0) == -1
     assert torch.equal(acc, before)
+
+
+def test_single_shard_reduce_scatter(binding, gpu_ctx):
+    """rt_reduce_scatter_rows with one shard: its band is the whole frame and the buffer is left as it was"""
+    import torch
+    lib = binding.lib()
+    W, H = 40, 30
+    sc = binding.Scene("cornell", W, H)
+    gpu_ctx.upload(sc)
+    acc = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    gpu_ctx.render_accumulate(acc, W, H, 0, 2, 419, 100, sc.background)
+    gpu_ctx.synchronize()
+    before = acc.clone()
+    a = (C.c_void_p * 1)(gpu_ctx.handle)
+    b = (C.c_void_p * 1)(acc.data_ptr())
+    rows = (C.c_int32 * 2)(-1, -1)
+    assert lib.rt_reduce_scatter_rows(a, b, 1, W, H, rows) == 0, lib.rt_last_error()
+    gpu_ctx.synchronize()
+    assert list(rows) == [0, H] and torch.equal(acc, before)
+    assert lib.rt_reduce_scatter_rows(a, b, 1, W, 0, rows) == -1
+    assert lib.rt_reduce_scatter_rows(a, b, 1, W, H, None) == -1
+    assert lib.rt_reduce_scatter_rows(a, b, 0, W, H, rows) == -1
