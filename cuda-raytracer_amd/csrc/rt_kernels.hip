@@ -671,8 +671,8 @@ extern "C" int rt_render_accumulate_window(rt_ctx* c, int w, int h, int x0, int 
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     HIPCHK(hipEventRecord(e0, c->stream));
     /* auto: the wavefront form pays off as soon as a BVH is traversed.  Measured at 1920x1080 (tools/compare_integrators.py),
-     * wavefront / megakernel: 1M triangles 2.92, 200 k 2.27, 20 k 1.70; final scene (11 k or 1.4 k items) 2.18-2.62; Cornell +
-     * 1000-sphere cluster 2.18; 488 spheres in a world BVH 1.59; 16 boxes 0.62; no BVH at all (Cornell) 0.30. */
+     * wavefront / megakernel: 1M triangles 1.97, 200 k 1.61, 20 k 1.21; final scene (11 k or 1.4 k items) 2.29-2.41; Cornell +
+     * 1000-sphere cluster 1.51; 488 spheres in a world BVH 1.17; 16 boxes 0.48; no BVH at all (Cornell) 0.31. */
     const bool big = c->n_bvh_items >= RT_WF_AUTO_ITEMS;
     const bool wavefront = c->integrator == RT_INTEGRATOR_WAVEFRONT || (c->integrator == RT_INTEGRATOR_AUTO && big && c->stack4 <= WF_LDS_STACK + WF_OVF_STACK);
     c->last_integrator = wavefront ? RT_INTEGRATOR_WAVEFRONT : RT_INTEGRATOR_MEGAKERNEL;
