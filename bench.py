@@ -125,10 +125,25 @@ def main():
         sys.exit("bench.py: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # RT_BENCH_BACKEND=gloo is a rehearsal of the N > 1 flow on a box with fewer GPUs than ranks (ranks share
+    # the cards, collectives go through host copies); its rate means nothing and the line says so
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    def coll(fn, t, **kw):
+        if backend == "gloo":
+            c = t.cpu()
+            fn(c, **kw)
+            t.copy_(c)
+        else:
+            fn(t, **kw)
 
     b = entry.load_binding()
 
@@ -143,8 +158,12 @@ def main():
         has_bvh = flat.n_bvh_nodes > 0
         scene_bytes = (flat.n_objects * 128 + flat.n_ops * 16 + flat.n_materials * 16 + flat.n_textures * 40
                        + flat.n_image_bytes + flat.n_bvh_nodes * 32 + flat.n_bvh_items * 64)
-        stream = torch.cuda.current_stream(dev)
-        ctx = b.Context(local_rank, stream.cuda_stream)
+        # one stream for everything: torch's fills, the library's kernels and the collective's hand-over.  (A null
+        # stream handle would make the library create a stream of its own, unordered against torch's.)
+        stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(stream)
+        assert stream.cuda_stream != 0
+        ctx = b.Context(dev_index, stream.cuda_stream)
         ctx.upload(scene)
         ctx.set_integrator({"auto": 0, "megakernel": 1, "wavefront": 2}[args.integrator])
         accum = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
@@ -156,7 +175,7 @@ def main():
             s0 = (k * world + rank) * spp            # every step and rank renders fresh sample indices
             ctx.render_accumulate(accum, W, H, s0, s0 + spp, 419, 100, background)
             if world > 1:
-                dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+                coll(dist.reduce, accum, dst=0, op=dist.ReduceOp.SUM)
             if rank == 0:
                 rgb = ctx.resolve(accum, W, H, spp * world, gamma=True)
 
@@ -181,8 +200,8 @@ def main():
         tot = torch.tensor([float(c.rays), float(c.samples)], dtype=torch.float64, device=dev)
         tmax = torch.tensor([dt, c.render_ms / max(1, c.render_launches)], dtype=torch.float64, device=dev)
         if world > 1:
-            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            coll(dist.all_reduce, tot, op=dist.ReduceOp.SUM)
+            coll(dist.all_reduce, tmax, op=dist.ReduceOp.MAX)
         rays, samples = tot.tolist()
         dt, kernel_ms = tmax.tolist()
         ctx.close()
@@ -199,7 +218,7 @@ def main():
                        "width": W, "height": H, "spp_per_gpu": spp, "max_depth": 100,
                        "background": "sky" if background else "black", "bvh": has_bvh,
                        "integrator": "wavefront" if wavefront else "megakernel",
-                       "parallelism": "spp-shard x%d + RCCL reduce" % world if world > 1 else "single GPU"},
+                       "parallelism": ("spp-shard x%d + %s" % (world, "RCCL reduce" if backend == "nccl" else "gloo reduce (REHEARSAL, ranks share GPUs)")) if world > 1 else "single GPU"},
             "samples_per_s": samples / dt, "rays_per_sample": rays / max(1.0, samples),
             "image_mean": mean_rgb, "image_finite": finite,
         }

@@ -1,0 +1,41 @@
+"""bench.py end to end on a small frame: the JSON line's contract, and the image of its last step against a direct
+render of the same sample range (torch's fills, the library's kernels and the resolve must be ordered on one stream)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("workload,extra", [("cornell", []), ("tri_mesh", ["--param", "3000"])])
+def test_bench_line_and_image(binding, gpu_ctx, workload, extra):
+    import torch
+    W, H, spp, steps, warmup = 64, 48, 8, 3, 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--width", str(W), "--height", str(H),
+                        "--spp", str(spp), "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-extras"] + extra,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j
+    assert j["n_gpus"] == 1 and j["steps"] == steps and j["warmup"] == warmup and j["value"] > 0 and j["image_finite"]
+    assert j["config"]["workload"] == "%s_%dx%d_%dspp" % (workload, W, H, spp)
+    # the last step rendered samples [(warmup + steps - 1) * spp, + spp) into a zeroed buffer
+    name, param = ("cornell", 0) if workload == "cornell" else ("tri_mesh", 3000)
+    sc = binding.Scene(name, W, H, param)
+    gpu_ctx.upload(sc)
+    acc = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    s0 = (warmup + steps - 1) * spp
+    gpu_ctx.render_accumulate(acc, W, H, s0, s0 + spp, 419, 100, sc.background)
+    gpu_ctx.synchronize()
+    rgb = gpu_ctx.resolve(acc, W, H, spp, gamma=True)
+    gpu_ctx.synchronize()
+    assert abs(float(rgb.mean()) - j["image_mean"]) <= 1e-5 * max(1.0, abs(j["image_mean"]))
