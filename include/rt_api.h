@@ -79,7 +79,10 @@ int  rt_scene_default_background(const rt_scene* s);   /* RT_BG_* the scene is m
 void rt_scene_destroy(rt_scene* s);
 
 /* ---- context (replaces cudaSetDevice + the allocations of gpuRender, main.cu:555-595) ---- */
-/* stream: a hipStream_t to run on (e.g. torch's current stream) or NULL for a private one */
+/* stream: a hipStream_t to run on, or NULL for a private, non-blocking one.  NULL never means the device's default
+ * stream: work the caller enqueues elsewhere (fills of accum_dev, copies, collectives) is then NOT ordered against
+ * the library's kernels, and the caller orders it with rt_synchronize / its own synchronisation.  To share a stream
+ * with torch, make a torch.cuda.Stream current and pass its handle (bench.py). */
 int  rt_ctx_create(int device, void* stream, rt_ctx** out);
 void rt_ctx_destroy(rt_ctx* c);
 /* validates every index in the tables, then copies them to the device */
