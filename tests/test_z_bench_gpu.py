@@ -39,3 +39,27 @@ def test_bench_line_and_image(binding, gpu_ctx, workload, extra):
     rgb = gpu_ctx.resolve(acc, W, H, spp, gamma=True)
     gpu_ctx.synchronize()
     assert abs(float(rgb.mean()) - j["image_mean"]) <= 1e-5 * max(1.0, abs(j["image_mean"]))
+
+
+def test_two_rank_flow_rehearsal():
+    """bench.py --gpus 2 under torch.distributed.run with RT_BENCH_BACKEND=gloo: both ranks share this box's GPU and the
+    collectives go through host copies, so only the flow is checked (sample shards, reduce onto rank 0, one JSON line
+    from rank 0, an image that is the mean over both ranks' samples)."""
+    W, H, spp = 64, 48, 8
+    env = dict(os.environ, RT_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--width", str(W), "--height", str(H), "--spp", str(spp), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common,
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["image_finite"] and "REHEARSAL" in j["config"]["parallelism"]
+    # the last step: rank r renders samples [(1 * 2 + r) * spp, + spp); together [2 spp, 4 spp) = one direct render
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + ["--width", str(W), "--height", str(H), "--spp", str(2 * spp), "--steps", "1",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    j1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])
+    assert abs(j1["image_mean"] - j["image_mean"]) <= 1e-5       # same samples, summed in another order
+    assert j["samples_per_s"] > 0 and abs(j["rays_per_sample"] - j1["rays_per_sample"]) < 1e-9
