@@ -270,9 +270,9 @@ def main():
     out = run(args.workload, args.width, args.height, args.spp, args.param, args.steps, args.warmup, True)
     if rank == 0:
         if world == 1 and args.workload == "cornell" and not args.no_extras:
-            # the north_star target scene beside the headline one: BASELINE.json configs[3] at reduced spp
-            # (the full 256 spp take ~1.3 s per step; the rate is the same from ~32 spp up)
-            extra = run("tri_mesh", 0, 0, 32, -1, 1, 1, False)
+            # the north_star target scene beside the headline one: BASELINE.json configs[3] as it stands
+            # (1M triangles, 1920x1080, 256 spp in one call: ~1.5 s per step)
+            extra = run("tri_mesh", 0, 0, 0, -1, 1, 1, False)
             out["also"] = [{k: extra[k] for k in ("value", "unit", "ms_per_step", "config", "samples_per_s", "rays_per_sample", "roofline")}]
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -56,7 +56,7 @@ def derived(wl, k):
 summary = {
     "cornell_1024x1024_1024spp": dict(derived("cornell", "render_kernel"), kernel="render_kernel", source=tag,
         traffic_bytes=(2.0 * g("cornell", "render_kernel", "FETCH_SIZE") + g("cornell", "render_kernel", "WRITE_SIZE")) * 1024.0),
-    "tri_mesh_1920x1080_32spp": dict(derived("tri", "wf_intersect_kernel"), kernel="wf_intersect_kernel", source=tag,
+    "tri_mesh_1920x1080_256spp": dict(derived("tri", "wf_intersect_kernel"), kernel="wf_intersect_kernel", source=tag,
         traffic_bytes=sum(v for (wl, k, c), v in allsum.items() if wl == "tri" and c in ("FETCH_SIZE", "WRITE_SIZE")) * 1024.0),
 }
 json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)

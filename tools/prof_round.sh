@@ -10,7 +10,7 @@ timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/cornell
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/cornell_write -- $C > $O/cornell_write.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY --output-format csv -d $O/cornell_sq -- $C > $O/cornell_sq.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH GRBM_GUI_ACTIVE --output-format csv -d $O/cornell_sq2 -- $C > $O/cornell_sq2.log 2>&1
-T="python3 bench.py --no-cpu-baseline --workload tri_mesh --spp 32 --steps 1 --warmup 0"
+T="python3 bench.py --no-cpu-baseline --workload tri_mesh --steps 1 --warmup 0"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_tri -- $T > $O/trace_tri.log 2>&1
 timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/tri_fetch -- $T > $O/tri_fetch.log 2>&1
 timeout -s KILL 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/tri_write -- $T > $O/tri_write.log 2>&1
