@@ -47,6 +47,10 @@
 #define RT_WF_SLOTS (1u << 27)
 #endif
 #define RT_N_COUNTERS 16        /* rays, samples, then diagnostic slots */
+#define WF_MAX_POOLS 4
+#ifndef WF_POOLS_DEFAULT
+#define WF_POOLS_DEFAULT 2
+#endif
 /* waves per SIMD each render-kernel variant is compiled for (its VGPR budget).  Measured on the Cornell
  * variant: 4 -> 19.7, 5 -> 20.6, 6 -> 21.1, 8 -> 18.1 Grays/s.  The kernel is VALU-issue bound and more waves
  * fill issue slots; 6 needs 80 VGPRs and spills 64 B/lane, which showed as 7.6 GB of scratch traffic per
@@ -339,7 +343,9 @@ struct rt_ctx {
     void* wf_mem = nullptr;
     size_t wf_slots_cap = 0;
     size_t wf_slots_target = RT_WF_SLOTS;   /* paths to keep in flight */
-    uint32_t* wf_host_count = nullptr;   /* pinned */
+    uint32_t* wf_host_count = nullptr;   /* pinned: 4 words of readback per pool, then the pools' first queue lengths */
+    hipStream_t wf_streams[WF_MAX_POOLS - 1] = {};    /* the other pools' streams */
+    hipEvent_t wf_ev[WF_MAX_POOLS + 1] = {};
     int stack_depth = 0;      /* LDS stack entries per lane the uploaded BVHs need */
     int stack4 = 1;           /* entries a traversal of the 4-wide trees can need (3 per level) */
     DScene ds;
@@ -399,6 +405,8 @@ extern "C" void rt_ctx_destroy(rt_ctx* c)
     if (c->wf_mem) (void)hipFree(c->wf_mem);
     if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->wf_host_count) (void)hipHostFree(c->wf_host_count);
+    for (hipStream_t st : c->wf_streams) if (st) (void)hipStreamDestroy(st);
+    for (hipEvent_t e : c->wf_ev) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -538,7 +546,9 @@ __global__ void wf_reset_kernel(uint32_t* count, int which) { count[which] = 0u;
 
 static int wf_reserve(rt_ctx* c, size_t n_slots)
 {
-    if (!c->wf_host_count) HIPCHK(hipHostMalloc((void**)&c->wf_host_count, 4 * sizeof(uint32_t), hipHostMallocDefault));
+    if (!c->wf_host_count) HIPCHK(hipHostMalloc((void**)&c->wf_host_count, 5 * WF_MAX_POOLS * sizeof(uint32_t), hipHostMallocDefault));
+    for (hipStream_t& st : c->wf_streams) if (!st) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (hipEvent_t& e : c->wf_ev) if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (n_slots > c->wf_slots_cap) {
         HIPCHK(hipStreamSynchronize(c->stream));
         if (c->wf_mem) { (void)hipFree(c->wf_mem); c->wf_mem = nullptr; c->wf_slots_cap = 0; }
@@ -597,41 +607,85 @@ static int wf_run(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t s1, u
     if (const char* e = std::getenv("RT_WF_REFILL")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) W.refill_min = v; }
     if (c->stack4 > WF_LDS_STACK + WF_OVF_STACK) { rt_set_error("wavefront integrator: BVH deeper than its traversal stack"); return RT_ERR_UNSUPPORTED; }
     const size_t lds = (size_t)(c->stack4 < WF_LDS_STACK ? c->stack4 : WF_LDS_STACK) * RT_BLOCK * sizeof(int);
-    HIPCHK(hipMemsetAsync(W.count, 0, 4 * sizeof(uint32_t), c->stream));
-    if (max_depth > 0) {       /* the first queue is every slot, in order (wf_init_kernel) */
-        c->wf_host_count[3] = (uint32_t)n_slots;
-        HIPCHK(hipMemcpyAsync(W.count, &c->wf_host_count[3], sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    }
-    const unsigned all_blocks = (unsigned)((n_slots + RT_BLOCK - 1) / RT_BLOCK);
-    wf_init_kernel<V><<<dim3(all_blocks), RT_BLOCK, 0, c->stream>>>(c->ds, W, w, h, s0, s1, k0, k1, max_depth, c->d_counters);
-    HIPCHK(hipGetLastError());
-    uint32_t known = (uint32_t)n_slots;      /* upper bound of the current queue's length (it never grows) */
-    int cur = 0;
-    const int batch = 4;
-    /* every iteration advances every live path by one bounce, and a slot runs at most ceil(samples / streams)
-     * paths of at most max_depth bounces: the loop cannot legitimately run longer than this */
-    const unsigned long long max_iters = ((unsigned long long)(s1 - s0 + streams - 1) / streams) * (unsigned long long)(max_depth > 0 ? max_depth : 1) + (unsigned)batch;
-    unsigned long long iters = 0;
-    while (known > 0) {
-        if (iters > max_iters) { rt_set_error("wavefront integrator: the path queue did not drain"); return RT_ERR_HIP; }
-        iters += (unsigned)batch;
-        for (int b = 0; b < batch; ++b) {
-            wf_reset_kernel<<<1, 1, 0, c->stream>>>(W.count, cur ^ 1);
-            unsigned blocks = (known + RT_BLOCK - 1) / RT_BLOCK;
-            unsigned iblocks = blocks < 2048u ? blocks : 2048u;
-            const unsigned lblocks = (known + RT_BLOCK * WF_LOGIC_TILES - 1) / (RT_BLOCK * WF_LOGIC_TILES);
-            wf_intersect_kernel<(V & ~RT_F_NOISE)><<<dim3(iblocks), RT_BLOCK, lds, c->stream>>>(c->ds, W, cur, k0, k1, c->d_counters);   /* reads no texture */
-            if (background == RT_BG_BLACK)
-                wf_logic_kernel<V, RT_BG_BLACK><<<dim3(lblocks), RT_BLOCK, 0, c->stream>>>(c->ds, W, cur, w, h, s1, k0, k1, max_depth);
-            else
-                wf_logic_kernel<V, RT_BG_SKY><<<dim3(lblocks), RT_BLOCK, 0, c->stream>>>(c->ds, W, cur, w, h, s1, k0, k1, max_depth);
-            cur ^= 1;
-        }
+    /* Two pools.  The slots are cut in two by sample stream and each half runs its own intersect / logic loop on a
+     * stream of its own: while one pool's intersect launch drains (its waves waiting for their last rays) or its
+     * logic kernel waits on memory, the other pool's intersect blocks take the free wave slots.  Pool 0 runs on the
+     * context's stream, pool 1 on a second one, fenced by events at both ends.  (RT_WF_POOLS=1: one pool.) */
+    int n_pools = WF_POOLS_DEFAULT;
+    if (const char* e = std::getenv("RT_WF_POOLS")) { const int v = std::atoi(e); if (v >= 1 && v <= WF_MAX_POOLS) n_pools = v; }
+    if ((uint32_t)n_pools > streams) n_pools = (int)streams;
+    struct Pool { WfState W; hipStream_t st; uint32_t known; int cur; bool pending; unsigned long long iters, max_iters; uint32_t* host; };
+    Pool pools[WF_MAX_POOLS];
+    W.stream0 = 0;
+    HIPCHK(hipMemsetAsync(W.count, 0, 4 * WF_MAX_POOLS * sizeof(uint32_t), c->stream));
+    for (int p = 0; p < n_pools; ++p) {
+        Pool& P = pools[p];
+        const uint32_t k_first = (uint32_t)((unsigned long long)streams * p / n_pools);
+        const uint32_t k_count = (uint32_t)((unsigned long long)streams * (p + 1) / n_pools) - k_first;
+        const size_t off = (size_t)k_first * n_pixels;
+        std::memcpy((void*)&P.W, (const void*)&W, sizeof(WfState));
+        P.W.ray_o += off; P.W.ray_d += off; P.W.att += off; P.W.sum += off; P.W.hit += off;
+        P.W.queue[0] += off; P.W.queue[1] += off;
+        P.W.count = W.count + 4 * p;
+        P.W.n_slots = k_count * n_pixels;
+        P.W.stream0 = k_first;
+        P.st = p == 0 ? c->stream : c->wf_streams[p - 1];
+        P.known = P.W.n_slots;             /* upper bound of the current queue's length (it never grows) */
+        P.cur = 0; P.pending = false; P.iters = 0;
+        P.host = c->wf_host_count + 4 * p;
+        /* every iteration advances every live path by one bounce, and a slot runs at most ceil(samples / streams)
+         * paths of at most max_depth bounces: the loop cannot legitimately run longer than this */
+        P.max_iters = ((unsigned long long)(s1 - s0 + streams - 1) / streams) * (unsigned long long)(max_depth > 0 ? max_depth : 1) + 4ull;
+        if (max_depth > 0) {               /* the first queue is every slot, in order (wf_init_kernel) */
+            c->wf_host_count[4 * WF_MAX_POOLS + p] = P.W.n_slots;
+            HIPCHK(hipMemcpyAsync(P.W.count, &c->wf_host_count[4 * WF_MAX_POOLS + p], sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        } else P.known = 0;
+        const unsigned all_blocks = (unsigned)((P.W.n_slots + RT_BLOCK - 1) / RT_BLOCK);
+        wf_init_kernel<V><<<dim3(all_blocks), RT_BLOCK, 0, c->stream>>>(c->ds, P.W, w, h, s0, s1, k0, k1, max_depth, c->d_counters);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(c->wf_host_count, W.count, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        known = c->wf_host_count[cur];
     }
+    if (n_pools > 1) {
+        HIPCHK(hipEventRecord(c->wf_ev[WF_MAX_POOLS], c->stream));
+        for (int p = 1; p < n_pools; ++p) HIPCHK(hipStreamWaitEvent(pools[p].st, c->wf_ev[WF_MAX_POOLS], 0));
+    }
+    const int batch = 4;
+    while (true) {
+        bool any = false;
+        for (int p = 0; p < n_pools; ++p) {
+            Pool& P = pools[p];
+            if (P.pending) {               /* the length its queue had after the previous batch */
+                HIPCHK(hipEventSynchronize(c->wf_ev[p]));
+                P.known = P.host[P.cur];
+                P.pending = false;
+            }
+            if (P.known == 0) continue;
+            any = true;
+            if (P.iters > P.max_iters) { rt_set_error("wavefront integrator: the path queue did not drain"); return RT_ERR_HIP; }
+            P.iters += (unsigned)batch;
+            for (int b = 0; b < batch; ++b) {
+                wf_reset_kernel<<<1, 1, 0, P.st>>>(P.W.count, P.cur ^ 1);
+                const unsigned blocks = (P.known + RT_BLOCK - 1) / RT_BLOCK;
+                const unsigned iblocks = blocks < 2048u ? blocks : 2048u;
+                const unsigned lblocks = (P.known + RT_BLOCK * WF_LOGIC_TILES - 1) / (RT_BLOCK * WF_LOGIC_TILES);
+                wf_intersect_kernel<(V & ~RT_F_NOISE)><<<dim3(iblocks), RT_BLOCK, lds, P.st>>>(c->ds, P.W, P.cur, k0, k1, c->d_counters);   /* reads no texture */
+                if (background == RT_BG_BLACK)
+                    wf_logic_kernel<V, RT_BG_BLACK><<<dim3(lblocks), RT_BLOCK, 0, P.st>>>(c->ds, P.W, P.cur, w, h, s1, k0, k1, max_depth);
+                else
+                    wf_logic_kernel<V, RT_BG_SKY><<<dim3(lblocks), RT_BLOCK, 0, P.st>>>(c->ds, P.W, P.cur, w, h, s1, k0, k1, max_depth);
+                P.cur ^= 1;
+            }
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(P.host, P.W.count, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, P.st));
+            HIPCHK(hipEventRecord(c->wf_ev[p], P.st));
+            P.pending = true;
+        }
+        if (!any) break;
+    }
+    for (int p = 1; p < n_pools; ++p) {     /* the other pools' last batches have been waited for on the host; order the streams too */
+        HIPCHK(hipEventRecord(c->wf_ev[p], pools[p].st));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->wf_ev[p], 0));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
     wf_finalize_kernel<<<dim3((n_pixels + RT_BLOCK - 1) / RT_BLOCK), RT_BLOCK, 0, c->stream>>>(W, accum);
     HIPCHK(hipGetLastError());
     return RT_OK;

@@ -35,7 +35,8 @@ struct WfState {
     float4* __restrict__ hit;     /* t, object, group, aux (bits) */
     uint32_t* __restrict__ queue[2];
     uint32_t* __restrict__ count; /* [0],[1] = entries of queue[0],queue[1]; [2] = intersect fetch head */
-    uint32_t n_slots, n_pixels, streams;    /* n_pixels = pixels of the rendered window */
+    uint32_t n_slots, n_pixels, streams;    /* n_pixels = pixels of the rendered window; streams = sample streams per pixel of the whole call */
+    uint32_t stream0;                       /* first stream of this pool (the slots of a call are run as one or two pools, rt_kernels.hip wf_run) */
     uint32_t win_x0, win_y0, win_w, frame_w;   /* the window inside the frame (rt_render_accumulate_window) */
     /* the world list for this integrator (rt_host.h rt_pack_program): its plain records, run in one go when a ray
      * is handed to a lane, and the BVH groups, walked one after the other by the step loop */
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_init_kernel(DScene S, WfState W, 
 {
     const uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (slot < W.n_slots) {
-        const uint32_t k = slot / W.n_pixels;
+        const uint32_t k = W.stream0 + slot / W.n_pixels;
         const uint32_t s = s_begin + k;
         W.sum[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (max_depth > 0) {
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_init_kernel(DScene S, WfState W, 
         }
     }
     /* samples counter: every sample of the range is rendered (black when max_depth is 0) */
-    if (slot == 0) atomicAdd(&counters[1], (unsigned long long)W.n_pixels * (unsigned long long)(s_end - s_begin));
+    if (slot == 0 && W.stream0 == 0) atomicAdd(&counters[1], (unsigned long long)W.n_pixels * (unsigned long long)(s_end - s_begin));
 }
 
 /* one queued path through one bounce; returns whether its slot goes on (with the same path or its next sample).
