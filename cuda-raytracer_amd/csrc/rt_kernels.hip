@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <chrono>
 #include <mutex>
 #include <cstdio>
 #include <cstdlib>
@@ -49,7 +50,7 @@
 #define RT_N_COUNTERS 16        /* rays, samples, then diagnostic slots */
 #define WF_MAX_POOLS 4
 #ifndef WF_POOLS_DEFAULT
-#define WF_POOLS_DEFAULT 2
+#define WF_POOLS_DEFAULT 3
 #endif
 /* waves per SIMD each render-kernel variant is compiled for (its VGPR budget).  Measured on the Cornell
  * variant: 4 -> 19.7, 5 -> 20.6, 6 -> 21.1, 8 -> 18.1 Grays/s.  The kernel is VALU-issue bound and more waves
@@ -344,7 +345,8 @@ struct rt_ctx {
     size_t wf_slots_cap = 0;
     size_t wf_slots_target = RT_WF_SLOTS;   /* paths to keep in flight */
     uint32_t* wf_host_count = nullptr;   /* pinned: 4 words of readback per pool, then the pools' first queue lengths */
-    hipStream_t wf_streams[WF_MAX_POOLS - 1] = {};    /* the other pools' streams */
+    hipStream_t wf_streams[WF_MAX_POOLS] = {};        /* the pools' streams: found to run side by side (wf_pick_streams) */
+    int wf_n_streams = -1;                            /* how many of them; -1 = not looked for yet */
     hipEvent_t wf_ev[WF_MAX_POOLS + 1] = {};
     int stack_depth = 0;      /* LDS stack entries per lane the uploaded BVHs need */
     int stack4 = 1;           /* entries a traversal of the 4-wide trees can need (3 per level) */
@@ -544,10 +546,58 @@ static int note_render(rt_ctx* c, hipEvent_t e0, hipEvent_t e1)
 /* ------------------------------------------------------------ wavefront host -- */
 __global__ void wf_reset_kernel(uint32_t* count, int which) { count[which] = 0u; count[2] = 0u; }
 
+/* Streams for the pools.  A process has few hardware queues (GPU_MAX_HW_QUEUES, 4 here) and the runtime spreads its
+ * streams over them; two streams on one queue run their kernels one after the other, and pools that do not overlap
+ * are worse than one pool.  Which streams share a queue cannot be asked, so it is measured once per context: a kernel
+ * that waits ~0.3 ms of wall clock is launched on a set of streams at once, and a candidate joins the set if the whole
+ * set still finishes in about one wait. */
+__global__ void wf_spin_kernel(unsigned long long ticks)
+{
+    const long long t0 = wall_clock64();                /* constant-rate counter, 100 MHz */
+    for (int i = 0; i < 100000; ++i) {                   /* bounded whatever the counter does */
+        if ((unsigned long long)(wall_clock64() - t0) >= ticks) break;
+        __builtin_amdgcn_s_sleep(16);
+    }
+}
+static int wf_pick_streams(rt_ctx* c)
+{
+    c->wf_n_streams = 0;
+    const unsigned long long ticks = 30000ull;          /* 0.3 ms */
+    auto timed = [&](hipStream_t extra, double& ms) -> int {
+        for (int i = 0; i < c->wf_n_streams; ++i) HIPCHK(hipStreamSynchronize(c->wf_streams[i]));
+        HIPCHK(hipStreamSynchronize(extra));
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < c->wf_n_streams; ++i) wf_spin_kernel<<<1, 64, 0, c->wf_streams[i]>>>(ticks);
+        wf_spin_kernel<<<1, 64, 0, extra>>>(ticks);
+        HIPCHK(hipGetLastError());
+        for (int i = 0; i < c->wf_n_streams; ++i) HIPCHK(hipStreamSynchronize(c->wf_streams[i]));
+        HIPCHK(hipStreamSynchronize(extra));
+        ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return RT_OK;
+    };
+    double one = 0.0;
+    std::vector<hipStream_t> rejected;      /* kept alive until the end: a stream made right after one was destroyed takes its queue again */
+    int rc = RT_OK;
+    for (int tries = 0; tries < 12 && c->wf_n_streams < WF_MAX_POOLS && rc == RT_OK; ++tries) {
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+        double ms = 0.0;
+        rc = timed(st, ms);
+        if (rc == RT_OK && tries == 0) rc = timed(st, ms);      /* the first launch also loads the kernel */
+        if (rc != RT_OK) { rejected.push_back(st); break; }
+        if (c->wf_n_streams == 0) one = ms;
+        if (std::getenv("RT_WF_DEBUG")) std::fprintf(stderr, "wf_pick_streams: candidate %d with %d chosen: %.3f ms (one: %.3f)\n", tries, c->wf_n_streams, ms, one);
+        if (c->wf_n_streams == 0 || ms < 1.6 * one) c->wf_streams[c->wf_n_streams++] = st;
+        else rejected.push_back(st);
+    }
+    for (hipStream_t st : rejected) (void)hipStreamDestroy(st);
+    if (rc != RT_OK) return rc;
+    return RT_OK;
+}
+
 static int wf_reserve(rt_ctx* c, size_t n_slots)
 {
     if (!c->wf_host_count) HIPCHK(hipHostMalloc((void**)&c->wf_host_count, 5 * WF_MAX_POOLS * sizeof(uint32_t), hipHostMallocDefault));
-    for (hipStream_t& st : c->wf_streams) if (!st) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     for (hipEvent_t& e : c->wf_ev) if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (n_slots > c->wf_slots_cap) {
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -607,13 +657,25 @@ static int wf_run(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t s1, u
     if (const char* e = std::getenv("RT_WF_REFILL")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) W.refill_min = v; }
     if (c->stack4 > WF_LDS_STACK + WF_OVF_STACK) { rt_set_error("wavefront integrator: BVH deeper than its traversal stack"); return RT_ERR_UNSUPPORTED; }
     const size_t lds = (size_t)(c->stack4 < WF_LDS_STACK ? c->stack4 : WF_LDS_STACK) * RT_BLOCK * sizeof(int);
-    /* Two pools.  The slots are cut in two by sample stream and each half runs its own intersect / logic loop on a
-     * stream of its own: while one pool's intersect launch drains (its waves waiting for their last rays) or its
-     * logic kernel waits on memory, the other pool's intersect blocks take the free wave slots.  Pool 0 runs on the
-     * context's stream, pool 1 on a second one, fenced by events at both ends.  (RT_WF_POOLS=1: one pool.) */
+    /* Pools.  The slots are cut into three pools by sample stream and each pool runs its own intersect / logic loop
+     * on a stream of its own, with a persistent intersect grid of a third of the size: while one pool's intersect
+     * launch drains (its waves waiting for their last rays) or its logic kernel waits on memory, the other pools'
+     * intersect blocks have the wave slots.  The pools run on streams of the context that were found to overlap
+     * (wf_pick_streams), fenced against the context's own stream by events at both ends.  Measured (tools/iblocks_sweep.sh; final scene 1080p x 64 spp / 1M
+     * triangles x 32 spp / x 256 spp, Grays/s): 1 pool x 2048 blocks 3.24 / 2.14 / 2.51; 2 x 2048 3.46 / 2.19 / 2.56;
+     * 2 x 1024 3.43 / 2.39 / 2.68; 3 x 768 3.62 / 2.47 / 2.68; 4 x 512 3.62 / 2.51 / 2.71.  Four pools are not
+     * used: the process has 4 hardware queues (GPU_MAX_HW_QUEUES), and as soon as two pools share one their small
+     * grids run one after the other on a half-empty chip (1M triangles in 64-spp chunks from a context with a stream
+     * of its own: 1 pool 2.30, 2 pools 2.55, 3 pools 2.57, 4 pools 2.15).
+     * RT_WF_POOLS and RT_WF_IBLOCKS in the environment override the two numbers. */
     int n_pools = WF_POOLS_DEFAULT;
     if (const char* e = std::getenv("RT_WF_POOLS")) { const int v = std::atoi(e); if (v >= 1 && v <= WF_MAX_POOLS) n_pools = v; }
     if ((uint32_t)n_pools > streams) n_pools = (int)streams;
+    if (n_pools > 1) {
+        if (c->wf_n_streams < 0) { int prc = wf_pick_streams(c); if (prc) return prc; }
+        if (n_pools > c->wf_n_streams) n_pools = c->wf_n_streams;
+        if (n_pools < 2) n_pools = 1;          /* no two streams that overlap: one pool on the context's stream */
+    }
     struct Pool { WfState W; hipStream_t st; uint32_t known; int cur; bool pending; unsigned long long iters, max_iters; uint32_t* host; };
     Pool pools[WF_MAX_POOLS];
     W.stream0 = 0;
@@ -629,7 +691,7 @@ static int wf_run(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t s1, u
         P.W.count = W.count + 4 * p;
         P.W.n_slots = k_count * n_pixels;
         P.W.stream0 = k_first;
-        P.st = p == 0 ? c->stream : c->wf_streams[p - 1];
+        P.st = n_pools == 1 ? c->stream : c->wf_streams[p];
         P.known = P.W.n_slots;             /* upper bound of the current queue's length (it never grows) */
         P.cur = 0; P.pending = false; P.iters = 0;
         P.host = c->wf_host_count + 4 * p;
@@ -646,8 +708,11 @@ static int wf_run(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t s1, u
     }
     if (n_pools > 1) {
         HIPCHK(hipEventRecord(c->wf_ev[WF_MAX_POOLS], c->stream));
-        for (int p = 1; p < n_pools; ++p) HIPCHK(hipStreamWaitEvent(pools[p].st, c->wf_ev[WF_MAX_POOLS], 0));
+        for (int p = 0; p < n_pools; ++p) HIPCHK(hipStreamWaitEvent(pools[p].st, c->wf_ev[WF_MAX_POOLS], 0));
     }
+    /* the persistent intersect grids of all pools together: about 2048 blocks (1.6 - 2 x what the chip holds at once) */
+    unsigned iblocks_max = 2048u / (unsigned)n_pools;
+    if (const char* e = std::getenv("RT_WF_IBLOCKS")) { const int v = std::atoi(e); if (v > 0) iblocks_max = (unsigned)v; }
     const int batch = 4;
     while (true) {
         bool any = false;
@@ -665,7 +730,7 @@ static int wf_run(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t s1, u
             for (int b = 0; b < batch; ++b) {
                 wf_reset_kernel<<<1, 1, 0, P.st>>>(P.W.count, P.cur ^ 1);
                 const unsigned blocks = (P.known + RT_BLOCK - 1) / RT_BLOCK;
-                const unsigned iblocks = blocks < 2048u ? blocks : 2048u;
+                const unsigned iblocks = blocks < iblocks_max ? blocks : iblocks_max;
                 const unsigned lblocks = (P.known + RT_BLOCK * WF_LOGIC_TILES - 1) / (RT_BLOCK * WF_LOGIC_TILES);
                 wf_intersect_kernel<(V & ~RT_F_NOISE)><<<dim3(iblocks), RT_BLOCK, lds, P.st>>>(c->ds, P.W, P.cur, k0, k1, c->d_counters);   /* reads no texture */
                 if (background == RT_BG_BLACK)
@@ -681,7 +746,7 @@ static int wf_run(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t s1, u
         }
         if (!any) break;
     }
-    for (int p = 1; p < n_pools; ++p) {     /* the other pools' last batches have been waited for on the host; order the streams too */
+    for (int p = 0; p < n_pools && n_pools > 1; ++p) {     /* the pools' last batches have been waited for on the host; order the streams too */
         HIPCHK(hipEventRecord(c->wf_ev[p], pools[p].st));
         HIPCHK(hipStreamWaitEvent(c->stream, c->wf_ev[p], 0));
     }
