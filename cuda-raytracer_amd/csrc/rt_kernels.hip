@@ -661,12 +661,11 @@ static int wf_run(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t s1, u
      * on a stream of its own, with a persistent intersect grid of a third of the size: while one pool's intersect
      * launch drains (its waves waiting for their last rays) or its logic kernel waits on memory, the other pools'
      * intersect blocks have the wave slots.  The pools run on streams of the context that were found to overlap
-     * (wf_pick_streams), fenced against the context's own stream by events at both ends.  Measured (tools/iblocks_sweep.sh; final scene 1080p x 64 spp / 1M
-     * triangles x 32 spp / x 256 spp, Grays/s): 1 pool x 2048 blocks 3.24 / 2.14 / 2.51; 2 x 2048 3.46 / 2.19 / 2.56;
-     * 2 x 1024 3.43 / 2.39 / 2.68; 3 x 768 3.62 / 2.47 / 2.68; 4 x 512 3.62 / 2.51 / 2.71.  Four pools are not
-     * used: the process has 4 hardware queues (GPU_MAX_HW_QUEUES), and as soon as two pools share one their small
-     * grids run one after the other on a half-empty chip (1M triangles in 64-spp chunks from a context with a stream
-     * of its own: 1 pool 2.30, 2 pools 2.55, 3 pools 2.57, 4 pools 2.15).
+     * (wf_pick_streams), fenced against the context's own stream by events at both ends.
+     * Measured (tools/iblocks_sweep.sh; final scene 1080p x 64 spp / 1M triangles x 32 spp / x 256 spp, Grays/s):
+     * 1 pool x 2048 blocks 3.24 / 2.14 / 2.51; 2 x 2048 3.46 / 2.19 / 2.56; 2 x 1024 3.43 / 2.39 / 2.68;
+     * 3 x 682 3.59 / 2.45 / 2.66; 4 x 512 3.62 / 2.51 / 2.71.  Three are used: the process has 4 hardware queues
+     * (GPU_MAX_HW_QUEUES) and one stays free for the caller's own streams.
      * RT_WF_POOLS and RT_WF_IBLOCKS in the environment override the two numbers. */
     int n_pools = WF_POOLS_DEFAULT;
     if (const char* e = std::getenv("RT_WF_POOLS")) { const int v = std::atoi(e); if (v >= 1 && v <= WF_MAX_POOLS) n_pools = v; }
