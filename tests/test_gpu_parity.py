@@ -442,3 +442,26 @@ def test_wavefront_with_a_small_path_pool(binding, gpu_ctx, monkeypatch):
                 assert torch.equal(got, ref)        # one stream: the megakernel's summation order, hence its bits
         finally:
             ctx.close()
+
+
+def test_wavefront_pools_do_not_change_the_image(binding, gpu_ctx, monkeypatch):
+    """the wavefront form cuts its path slots into pools that run side by side on streams of their own (RT_WF_POOLS,
+    default 3); slots are independent, so one pool, three and four give the same bits and the same ray count"""
+    import torch
+    W, H, spp = 96, 64, 12
+    for name, param in (("tri_mesh", 3000), ("final", 8)):
+        sc = binding.Scene(name, W, H, param)
+        gpu_ctx.upload(sc)
+        images, rays = [], []
+        for pools in ("1", None, "4", "2"):
+            if pools is None:
+                monkeypatch.delenv("RT_WF_POOLS", raising=False)
+            else:
+                monkeypatch.setenv("RT_WF_POOLS", pools)
+            gpu_ctx.reset_counters()
+            images.append(render_gpu(gpu_ctx, binding, sc, W, H, 3, 3 + spp, 77, integrator="wavefront"))
+            rays.append(gpu_ctx.counters().rays)
+        monkeypatch.delenv("RT_WF_POOLS", raising=False)
+        assert float(images[0].sum()) > 0
+        for im, r in zip(images[1:], rays[1:]):
+            assert torch.equal(im, images[0]) and r == rays[0]
