@@ -52,18 +52,18 @@
 #ifndef WF_POOLS_DEFAULT
 #define WF_POOLS_DEFAULT 3
 #endif
-/* waves per SIMD each render-kernel variant is compiled for (its VGPR budget).  Measured on the Cornell
- * variant: 4 -> 19.7, 5 -> 20.6, 6 -> 21.1, 8 -> 18.1 Grays/s.  The kernel is VALU-issue bound and more waves
- * fill issue slots; 6 needs 80 VGPRs and spills 64 B/lane, which showed as 7.6 GB of scratch traffic per
- * launch against 26 MB of algorithmic bytes, so the spill-free 5 is used.  The larger variants spill earlier. */
+/* waves per SIMD each render-kernel variant is compiled for (its VGPR budget).  The kernels are VALU-issue bound and
+ * more waves fill issue slots, until the spills cost more.  Measured on the Cornell variant (current build): 5 waves
+ * (96 VGPRs, no spill) 25.4 Grays/s, 6 (80 VGPRs, 9 spilled, 40 B of scratch per lane) 26.6, 7 (72 VGPRs, 28
+ * spilled) 26.0; an early build read 4 -> 19.7, 5 -> 20.6, 6 -> 21.1, 8 -> 18.1.  Cornell smoke: 4 -> 22.6, 5 -> 24.2,
+ * 6 -> 24.8.  The spills show up as scratch traffic in the counters (profiles/), far from any bandwidth limit. */
 constexpr int rt_render_waves(uint32_t F)
 {
 #ifndef RT_PLANAR_WAVES
-#define RT_PLANAR_WAVES 5
+#define RT_PLANAR_WAVES 6
 #endif
-    /* the Cornell-smoke variant: 4 -> 22.6, 5 -> 24.2 Grays/s (96 VGPRs, 4 of them spilled) */
 #ifndef RT_MEDIA_WAVES
-#define RT_MEDIA_WAVES 5
+#define RT_MEDIA_WAVES 6
 #endif
     return (F & RT_F_BVH) ? 3 : ((F & ~(RT_F_PLANAR | RT_F_XFORM)) == 0 ? RT_PLANAR_WAVES : ((F & ~(RT_F_PLANAR | RT_F_XFORM | RT_F_MEDIA | RT_F_ISO)) == 0 ? RT_MEDIA_WAVES : 4));
 }
