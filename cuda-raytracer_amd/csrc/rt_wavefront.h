@@ -64,7 +64,7 @@ __device__ __forceinline__ uint32_t wf_frame_pixel(const WfState& W, uint32_t sl
 
 enum { WF_NEED = 0, WF_BVH = 2 };
 /* waves per SIMD the intersect kernel is compiled for: the triangle-mesh variant fits 96 VGPRs without spilling
- * (5 waves: +1.5 % on the 1M-triangle scene); the general ones spill at 5 (final scene: all-feature variant -27 %,
+ * (5 waves: +1.5 % on the 1M-triangle scene; 6 waves = 80 VGPRs with 14 spilled: -16 %); the general ones spill at 5 (final scene: all-feature variant -27 %,
  * the one without triangles, 19 spilled registers, -9 %) */
 #ifndef WF_GENERAL_WAVES
 #define WF_GENERAL_WAVES 4
