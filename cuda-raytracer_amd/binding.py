@@ -76,7 +76,7 @@ HIT_DTYPE = [("hit", "<i4"), ("prim", "<i4"), ("t", "<f4"), ("u", "<f4"), ("v", 
 EXPORTS = [
     "rt_last_error", "rt_scene_create_builtin", "rt_scene_from_flat", "rt_scene_flat",
     "rt_scene_default_background", "rt_scene_destroy", "rt_ctx_create", "rt_ctx_destroy",
-    "rt_scene_upload", "rt_trace_rays", "rt_trace_primary", "rt_render_accumulate", "rt_render_accumulate_window", "rt_resolve",
+    "rt_scene_upload", "rt_trace_rays", "rt_trace_primary", "rt_render_accumulate", "rt_render_accumulate_window", "rt_render_accumulate_noalloc", "rt_resolve",
     "rt_ctx_set_integrator", "rt_reduce_accum", "rt_reduce_scatter_rows", "rt_synchronize", "rt_get_counters", "rt_reset_counters", "rt_quantise_rgb8", "rt_write_ppm", "rt_write_png", "rt_read_ppm", "rt_free_pixels", "rt_flat_features", "rt_flat_program", "rt_flat_program_split", "rt_flat_bvh_stats",
 ]
 
@@ -106,6 +106,7 @@ def load_library(path=LIB_PATH):
     lib.rt_trace_primary.argtypes = [vp, i32, i32, f32, f32, vp, vp]
     lib.rt_render_accumulate.argtypes = [vp, i32, i32, u32, u32, u64, i32, i32, vp]
     lib.rt_render_accumulate_window.argtypes = [vp, i32, i32, i32, i32, i32, i32, u32, u32, u64, i32, i32, vp]
+    lib.rt_render_accumulate_noalloc.argtypes = [vp, i32, i32, u32, u32, u64, i32, i32, vp]
     lib.rt_resolve.argtypes = [vp, vp, i32, i32, u32, i32, vp]
     lib.rt_ctx_set_integrator.argtypes = [vp, i32]
     lib.rt_reduce_accum.argtypes = [C.POINTER(vp), C.POINTER(vp), i32, u64, i32]
@@ -209,6 +210,13 @@ class Context:
         assert accum.is_cuda and accum.dtype == torch.float32 and accum.is_contiguous() and accum.numel() == width * height * 3
         _check(lib().rt_render_accumulate(self.handle, width, height, s0, s1, seed, max_depth, background, accum.data_ptr()),
                "rt_render_accumulate")
+
+    def render_accumulate_noalloc(self, accum, width, height, s0, s1, seed, max_depth=100, background=RT_BG_BLACK):
+        """megakernel form with the library's built-in scratch: no allocation inside the call"""
+        import torch
+        assert accum.is_cuda and accum.dtype == torch.float32 and accum.is_contiguous() and accum.numel() == width * height * 3
+        _check(lib().rt_render_accumulate_noalloc(self.handle, width, height, s0, s1, seed, max_depth, background, accum.data_ptr()),
+               "rt_render_accumulate_noalloc")
 
     def render_window(self, accum, width, height, window, s0, s1, seed, max_depth=100, background=RT_BG_BLACK):
         """window = (x0, y0, x1, y1) inside the width x height frame; accum is the full frame's buffer"""

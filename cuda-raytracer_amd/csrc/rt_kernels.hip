@@ -80,6 +80,14 @@ constexpr int rt_render_waves(uint32_t F)
 #define RT_STAMP_FLUSH
 #endif
 
+/* Scratch of rt_render_accumulate_noalloc (include/rt_api.h): the per-run partial frames of the megakernel, for callers
+ * that cannot allocate.  One array per GPU the library runs on, held until the process ends.  RT_NOALLOC_FLOATS =
+ * 16 runs x 512 x 512 pixels x 3 floats = 48 MiB.  In host code the array's name is only a stand-in: the device address
+ * is looked up once per device (noalloc_scratch_for) and only that pointer is handed to kernels. */
+#define RT_NOALLOC_FLOATS (16u * 512u * 512u * 3u)
+#define RT_MAX_DEVICES 64
+static __device__ __align__(256) float rt_noalloc_scratch[RT_NOALLOC_FLOATS];
+
 /* ------------------------------------------------------------------ kernels -- */
 template <uint32_t F>
 __global__ __launch_bounds__(RT_BLOCK) void trace_rays_kernel(DScene S, int n, const float* __restrict__ rays,
@@ -375,6 +383,25 @@ static void free_scene(rt_ctx* c)
     c->have_scene = false;
 }
 
+/* device address of rt_noalloc_scratch on `device`, looked up once per device with that device current
+ * (every GPU holds its own copy of the array at its own address) */
+static float* g_noalloc_ptr[RT_MAX_DEVICES];
+static std::mutex g_noalloc_mutex;
+static int noalloc_scratch_for(int device, float** out)
+{
+    if (device < 0 || device >= RT_MAX_DEVICES) { rt_set_error("no-allocation scratch: device index beyond the table"); return RT_ERR_ARG; }
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+    if (!g_noalloc_ptr[device]) {
+        HIPCHK(hipSetDevice(device));
+        float* p = nullptr;
+        HIPCHK(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(rt_noalloc_scratch)));
+        if (!p) { rt_set_error("no-allocation scratch: hipGetSymbolAddress returned null"); return RT_ERR_HIP; }
+        g_noalloc_ptr[device] = p;
+    }
+    if (out) *out = g_noalloc_ptr[device];
+    return RT_OK;
+}
+
 extern "C" int rt_ctx_create(int device, void* stream, rt_ctx** out)
 {
     if (!out) { rt_set_error("rt_ctx_create: null out"); return RT_ERR_ARG; }
@@ -382,6 +409,7 @@ extern "C" int rt_ctx_create(int device, void* stream, rt_ctx** out)
     HIPCHK(hipGetDeviceCount(&n));
     if (device < 0 || device >= n) { rt_set_error("rt_ctx_create: no such device"); return RT_ERR_ARG; }
     HIPCHK(hipSetDevice(device));
+    { int src = noalloc_scratch_for(device, nullptr); if (src) return src; }
     rt_ctx* c = new rt_ctx();
     c->device = device;
     if (const char* e = std::getenv("RT_WF_SLOTS")) { const long long v = std::atoll(e); if (v > 0) c->wf_slots_target = (size_t)v; }
@@ -759,6 +787,58 @@ static int wf_run(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t s1, u
     return RT_OK;
 }
 
+/* Runs of the megakernel.  The sample range is cut into up to 16 runs of >= 64 samples, and a block renders one run each of
+ * as many tiles spread over the frame, its lanes walking through them independently (render_kernel).  Measured on the
+ * Cornell box, 1024 x 1024 x 1024 spp: 1 run (a wave stays on one tile until its slowest pixel is done) 20.9 Grays/s
+ * before this and 19.2 with the walking code in the loop; 4 runs 20.5, 8 runs 23.6, 16 runs 24.5, 32-128 runs 24.5.
+ * The number of runs depends on the sample count only, so a window and the full frame group a pixel's samples
+ * alike; calls of fewer than 128 samples have one run and sum a pixel's samples in order. */
+static void mega_runs(uint32_t n_samples, uint32_t& groups, uint32_t& per_group)
+{
+    groups = n_samples / 64u;
+    groups = groups < 1u ? 1u : (groups > 16u ? 16u : groups);
+    /* RT_MEGA_GROUPS in the environment overrides the number of runs (how the figures above were measured) */
+    if (const char* e = std::getenv("RT_MEGA_GROUPS")) { groups = (uint32_t)std::atoi(e); if (groups < 1 || groups > n_samples) groups = 1; }
+    per_group = (n_samples + groups - 1) / groups;
+    groups = (n_samples + per_group - 1) / per_group;
+}
+
+/* render_kernel (+ combine_kernel when the runs' frames go through `partial`) on the context's stream */
+static hipError_t mega_launch(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t s1, uint32_t k0, uint32_t k1, int max_depth,
+                              int background, float* accum, uint32_t groups, uint32_t per_group, float* partial)
+{
+    const size_t lds = RT_BLOCK * sizeof(int) + stack_bytes(c);
+    dim3 grid(n_tiles(win.z, win.w));
+    if (!partial) groups = 1;
+    const uint32_t per = groups > 1 ? per_group : s1 - s0;
+    /* block B takes run k of tile (B + k * tile_step) mod n_tiles: steps of about 0.38 of the frame */
+    uint32_t tile_step = (uint32_t)(grid.x * 0.3819660113);
+    if (tile_step == 0) tile_step = 1;
+    /* the smallest compiled feature set that covers the scene */
+    static const uint32_t variants[] = {RT_V_PLANAR, RT_V_PLANAR_MEDIA, RT_V_LIST, RT_V_BVH_TRI, RT_F_ALL, RT_V_NOISE};
+    uint32_t pick = RT_V_NOISE;
+    for (uint32_t v : variants) if ((c->features & ~v) == 0) { pick = v; break; }
+#define RT_LAUNCH(V, G) render_kernel<V, G><<<grid, RT_BLOCK, lds, c->stream>>>(c->ds, w, h, win, s0, s1, k0, k1, max_depth, accum, c->d_counters, per, partial, groups, tile_step)
+#define RT_LAUNCH_BG(V) { if (background == RT_BG_BLACK) RT_LAUNCH(V, RT_BG_BLACK); else RT_LAUNCH(V, RT_BG_SKY); }
+    switch (pick) {
+    case RT_V_PLANAR:       RT_LAUNCH_BG(RT_V_PLANAR) break;
+    case RT_V_PLANAR_MEDIA: RT_LAUNCH_BG(RT_V_PLANAR_MEDIA) break;
+    case RT_V_LIST:         RT_LAUNCH_BG(RT_V_LIST) break;
+    case RT_V_BVH_TRI:      RT_LAUNCH_BG(RT_V_BVH_TRI) break;
+    case RT_F_ALL:          RT_LAUNCH_BG(RT_F_ALL) break;
+    default:                RT_LAUNCH_BG(RT_V_NOISE) break;
+    }
+#undef RT_LAUNCH_BG
+#undef RT_LAUNCH
+    hipError_t le = hipGetLastError();
+    if (le == hipSuccess && partial) {
+        const size_t n_win = (size_t)win.z * win.w * 3;
+        combine_kernel<<<dim3((unsigned)((n_win + RT_BLOCK - 1) / RT_BLOCK)), RT_BLOCK, 0, c->stream>>>(accum, partial, w, h, win, (int)groups);
+        le = hipGetLastError();
+    }
+    return le;
+}
+
 extern "C" int rt_ctx_set_integrator(rt_ctx* c, int mode)
 {
     if (!c || mode < RT_INTEGRATOR_AUTO || mode > RT_INTEGRATOR_WAVEFRONT) { rt_set_error("rt_ctx_set_integrator: bad arguments"); return RT_ERR_ARG; }
@@ -789,7 +869,6 @@ extern "C" int rt_render_accumulate_window(rt_ctx* c, int w, int h, int x0, int 
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
-    dim3 grid(n_tiles(win.z, win.w));
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     HIPCHK(hipEventRecord(e0, c->stream));
     /* auto: the wavefront form pays off as soon as a BVH is traversed.  Measured at 1920x1080 (tools/compare_integrators.py),
@@ -808,20 +887,8 @@ extern "C" int rt_render_accumulate_window(rt_ctx* c, int w, int h, int x0, int 
         int nrc = note_render(c, e0, e1);
         return wrc ? wrc : nrc;
     }
-    const size_t lds = RT_BLOCK * sizeof(int) + stack_bytes(c);
-    /* Runs.  The sample range is cut into up to 16 runs of >= 64 samples, and a block renders one run each of as many
-     * tiles spread over the frame, its lanes walking through them independently (render_kernel).  Measured on the
-     * Cornell box, 1024 x 1024 x 1024 spp: 1 run (a wave stays on one tile until its slowest pixel is done) 20.9 Grays/s
-     * before this and 19.2 with the walking code in the loop; 4 runs 20.5, 8 runs 23.6, 16 runs 24.5, 32-128 runs 24.5.
-     * The number of runs depends on the sample count only, so a window and the full frame group a pixel's samples
-     * alike; calls of fewer than 128 samples have one run and sum a pixel's samples in order. */
-    const uint32_t n_samples = s1 - s0;
-    uint32_t groups = n_samples / 64u;
-    groups = groups < 1u ? 1u : (groups > 16u ? 16u : groups);
-    /* RT_MEGA_GROUPS in the environment overrides the number of runs (how the figures above were measured) */
-    if (const char* e = std::getenv("RT_MEGA_GROUPS")) { groups = (uint32_t)std::atoi(e); if (groups < 1 || groups > n_samples) groups = 1; }
-    const uint32_t per_group = (n_samples + groups - 1) / groups;
-    groups = (n_samples + per_group - 1) / per_group;
+    uint32_t groups, per_group;
+    mega_runs(s1 - s0, groups, per_group);
     float* partial = nullptr;
     if (groups > 1) {
         const size_t need = (size_t)groups * (size_t)w * (size_t)h * 3;
@@ -833,36 +900,44 @@ extern "C" int rt_render_accumulate_window(rt_ctx* c, int w, int h, int x0, int 
         }
         partial = groups > 1 ? c->d_partial : nullptr;
     }
-    const uint32_t per = groups > 1 ? per_group : n_samples;
-    /* block B takes run k of tile (B + k * tile_step) mod n_tiles: steps of about 0.38 of the frame */
-    uint32_t tile_step = (uint32_t)(grid.x * 0.3819660113);
-    if (tile_step == 0) tile_step = 1;
-    /* the smallest compiled feature set that covers the scene */
-    static const uint32_t variants[] = {RT_V_PLANAR, RT_V_PLANAR_MEDIA, RT_V_LIST, RT_V_BVH_TRI, RT_F_ALL, RT_V_NOISE};
-    uint32_t pick = RT_V_NOISE;
-    for (uint32_t v : variants) if ((c->features & ~v) == 0) { pick = v; break; }
-#define RT_LAUNCH(V, G) render_kernel<V, G><<<grid, RT_BLOCK, lds, c->stream>>>(c->ds, w, h, win, s0, s1, k0, k1, max_depth, accum, c->d_counters, per, partial, groups, tile_step)
-#define RT_LAUNCH_BG(V) { if (background == RT_BG_BLACK) RT_LAUNCH(V, RT_BG_BLACK); else RT_LAUNCH(V, RT_BG_SKY); }
-    switch (pick) {
-    case RT_V_PLANAR:       RT_LAUNCH_BG(RT_V_PLANAR) break;
-    case RT_V_PLANAR_MEDIA: RT_LAUNCH_BG(RT_V_PLANAR_MEDIA) break;
-    case RT_V_LIST:         RT_LAUNCH_BG(RT_V_LIST) break;
-    case RT_V_BVH_TRI:      RT_LAUNCH_BG(RT_V_BVH_TRI) break;
-    case RT_F_ALL:          RT_LAUNCH_BG(RT_F_ALL) break;
-    default:                RT_LAUNCH_BG(RT_V_NOISE) break;
-    }
-#undef RT_LAUNCH_BG
-#undef RT_LAUNCH
-    hipError_t le = hipGetLastError();
-    if (le == hipSuccess && partial) {
-        const size_t n_win = (size_t)win.z * win.w * 3;
-        combine_kernel<<<dim3((unsigned)((n_win + RT_BLOCK - 1) / RT_BLOCK)), RT_BLOCK, 0, c->stream>>>(accum, partial, w, h, win, (int)groups);
-        le = hipGetLastError();
-    }
+    hipError_t le = mega_launch(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum, groups, per_group, partial);
     HIPCHK(hipEventRecord(e1, c->stream));
     int nrc = note_render(c, e0, e1);
     if (le != hipSuccess) { rt_set_error(std::string("render launch failed: ") + hipGetErrorString(le)); return RT_ERR_HIP; }
     return nrc;
+}
+
+/* No counterpart in the reference (include/rt_api.h): rt_render_accumulate in megakernel form for callers that cannot
+ * allocate.  The per-run partial frames live in rt_noalloc_scratch (this GPU's copy, address looked up at rt_ctx_create);
+ * no hipMalloc / hipFree / event creation happens here, and the call is not timed (rt_counters' times skip it). */
+extern "C" int rt_render_accumulate_noalloc(rt_ctx* c, int w, int h, uint32_t s0, uint32_t s1, uint64_t seed, int max_depth,
+                                            int background, float* accum)
+{
+    int rc = need_scene(c, "rt_render_accumulate_noalloc");
+    if (rc) return rc;
+    if (!frame_ok(w, h) || !accum || s1 < s0 || max_depth < 0 || (background != RT_BG_BLACK && background != RT_BG_SKY)) {
+        rt_set_error("rt_render_accumulate_noalloc: bad arguments");
+        return RT_ERR_ARG;
+    }
+    if (s1 == s0) return RT_OK;
+    uint32_t groups, per_group;
+    mega_runs(s1 - s0, groups, per_group);
+    if (groups > 1 && (unsigned long long)groups * (unsigned long long)w * (unsigned long long)h * 3ull > (unsigned long long)RT_NOALLOC_FLOATS) {
+        rt_set_error("rt_render_accumulate_noalloc: " + std::to_string(groups) + " runs of a " + std::to_string(w) + "x" + std::to_string(h) +
+                     " frame need more than the " + std::to_string((unsigned long long)RT_NOALLOC_FLOATS * 4ull >> 20) +
+                     " MiB of built-in scratch (16 runs of 512x512 pixels); render fewer than 128 samples per call, a smaller frame, or use rt_render_accumulate");
+        return RT_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    float* scratch = nullptr;
+    if ((rc = noalloc_scratch_for(c->device, &scratch))) return rc;      /* a table lookup after rt_ctx_create */
+    c->last_integrator = RT_INTEGRATOR_MEGAKERNEL;
+    /* every (run, pixel) cell the combine step reads is written by the render kernel of the same call first (a pixel hands
+     * in each of its runs, black ones included), so what an earlier call left in the array is never read: nothing to clear */
+    hipError_t le = mega_launch(c, w, h, make_int4(0, 0, w, h), s0, s1, (uint32_t)seed, (uint32_t)(seed >> 32), max_depth, background,
+                                accum, groups, per_group, groups > 1 ? scratch : nullptr);
+    if (le != hipSuccess) { rt_set_error(std::string("render launch failed: ") + hipGetErrorString(le)); return RT_ERR_HIP; }
+    return RT_OK;
 }
 
 extern "C" int rt_resolve(rt_ctx* c, const float* accum, int w, int h, uint32_t spp, int gamma, float* rgb)

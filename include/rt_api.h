@@ -112,6 +112,18 @@ int  rt_render_accumulate(rt_ctx* c, int width, int height, uint32_t sample_begi
 int  rt_render_accumulate_window(rt_ctx* c, int width, int height, int x0, int y0, int x1, int y1,
                                  uint32_t sample_begin, uint32_t sample_end, uint64_t seed, int max_depth,
                                  int background, float* accum_dev);
+/* No counterpart in the reference.  rt_render_accumulate for callers that cannot allocate (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc): always the megakernel form, full frame, and the
+ * per-run partial frames that rt_render_accumulate keeps in a hipMalloc'ed per-context buffer live in a fixed
+ * 48 MiB array built into the library's device image (one copy per GPU the library runs on, held until the process
+ * ends).  The call makes no hipMalloc / hipFree / event or stream creation and is not timed (rt_counters' rays and
+ * samples count it, its times do not).  Limit: calls of >= 128 samples are cut into runs (up to 16), and
+ * runs x width x height x 3 floats must fit the array, i.e. up to 512 x 512 pixels at 16 runs; larger calls are refused
+ * with RT_ERR_ARG (calls of < 128 samples use no scratch and have no frame limit).  Same bits as
+ * rt_render_accumulate under RT_INTEGRATOR_MEGAKERNEL.  All calls on one GPU share that GPU's array: calls that
+ * overlap on one GPU (two contexts or streams) race; serialise them. */
+int  rt_render_accumulate_noalloc(rt_ctx* c, int width, int height, uint32_t sample_begin, uint32_t sample_end,
+                                  uint64_t seed, int max_depth, int background, float* accum_dev);
 /* Which form of the integrator rt_render_accumulate runs (no counterpart in the reference, whose render
  * kernel is one monolithic per-pixel loop, main.cu:125-198):
  *   RT_INTEGRATOR_MEGAKERNEL  one kernel, a path stays in its lane from camera to termination and the lane
