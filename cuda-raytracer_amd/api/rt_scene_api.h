@@ -332,28 +332,17 @@ public:
 };
 
 /* ------------------------------------------------------------------ camera -- */
+/* Same constructor signature as Camera.cuh:23.  Like every class here it only records: the nine arguments are kept
+ * as given and rt::lower() derives the 96-byte camera block of include/rt_scene.h from them (csrc/lower.cpp,
+ * camera_block, which cites the operation order it has to keep). */
 class Camera : public rt::Node {
 public:
     Camera(Vector3 lookfrom, Vector3 lookat, Vector3 vup, float vfov, float aspect, float aperture,
            float focusDist, float t0, float t1)
-    {
-        time0 = t0;
-        time1 = t1;
-        lensRadius = aperture / 2.f;
-        float theta = vfov * ((float)M_PI) / 180.f;
-        float halfHeight = std::tan(theta / 2);
-        float halfWidth = aspect * halfHeight;
-        origin = lookfrom;
-        w = unitVector(lookfrom - lookat);
-        u = unitVector(cross(vup, w));
-        v = cross(w, u);
-        lowerLeftCorner = origin - halfWidth * u * focusDist - halfHeight * v * focusDist - w * focusDist;
-        horizontal = 2.f * halfWidth * u * focusDist;
-        vertical = 2.f * halfHeight * v * focusDist;
-    }
-    Vector3 lowerLeftCorner, horizontal, vertical, origin;
-    Vector3 u, v, w;
-    float lensRadius, time0, time1;
+        : eye(lookfrom), target(lookat), upHint(vup), vfovDegrees(vfov), aspectRatio(aspect), apertureDiameter(aperture),
+          focusDistance(focusDist), shutterOpen(t0), shutterClose(t1) {}
+    Vector3 eye, target, upHint;
+    float vfovDegrees, aspectRatio, apertureDiameter, focusDistance, shutterOpen, shutterClose;
 };
 
 #endif /* RT_SCENE_API_H */

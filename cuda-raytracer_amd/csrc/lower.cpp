@@ -489,13 +489,44 @@ struct Lowerer {
     }
 };
 
+/* The camera block from the recorded constructor arguments.  The values must carry the roundings of the reference's
+ * constructor (Camera.cuh:23-39), so the order of the fp32 operations is the reference's: theta = (vfov * pi) / 180 with
+ * pi narrowed to float first; half height = tan(theta / 2) in float; basis w = unit(from - at), u = unit(up x w),
+ * v = w x u; corner = ((from - (hw * u) * fd) - (hh * v) * fd) - w * fd; spans = ((2 * hw) * u) * fd and ((2 * hh) * v) * fd;
+ * lens radius = aperture / 2.  Built with -ffp-contract=off like everything else here. */
+static void camera_block(const Camera& k, rt_camera& c)
+{
+    const float theta = k.vfovDegrees * ((float)M_PI) / 180.f;
+    const float hh = std::tan(theta / 2);
+    const float hw = k.aspectRatio * hh;
+    const float fd = k.focusDistance;
+    const Vector3 back = unitVector(k.eye - k.target);
+    const Vector3 right = unitVector(cross(k.upHint, back));
+    const Vector3 above = cross(back, right);
+    const float two_hw = 2.f * hw, two_hh = 2.f * hh;
+    for (int a = 0; a < 3; ++a) {
+        const float along_u = hw * right.e[a] * fd;
+        const float along_v = hh * above.e[a] * fd;
+        c.origin[a] = k.eye.e[a];
+        c.lower_left[a] = k.eye.e[a] - along_u - along_v - back.e[a] * fd;
+        c.horizontal[a] = two_hw * right.e[a] * fd;
+        c.vertical[a] = two_hh * above.e[a] * fd;
+        c.u[a] = right.e[a];
+        c.v[a] = above.e[a];
+        c.w[a] = back.e[a];
+    }
+    c.lens_radius = k.apertureDiameter / 2.f;
+    c.time0 = k.shutterOpen;
+    c.time1 = k.shutterClose;
+}
+
 bool lower(Hitable* world, const Camera* cam, const LowerOptions& opt, FlatScene& out, std::string& err)
 {
     out = FlatScene();
     Lowerer L(out, opt, err);
     if (!world || !cam) { err = "null world or camera"; return false; }
-    L.shutter0 = cam->time0;
-    L.shutter1 = cam->time1;
+    L.shutter0 = cam->shutterOpen;
+    L.shutter1 = cam->shutterClose;
     /* the root is always a GROUP; a bare object becomes a one-element world */
     out.objects.resize(1);
     if (world->kind() == Hitable::LIST || world->kind() == Hitable::BVH) {
@@ -507,19 +538,7 @@ bool lower(Hitable* world, const Camera* cam, const LowerOptions& opt, FlatScene
     }
     if (!L.ok) return false;
 
-    rt_camera& c = out.view.camera;
-    for (int i = 0; i < 3; ++i) {
-        c.lower_left[i] = cam->lowerLeftCorner.e[i];
-        c.horizontal[i] = cam->horizontal.e[i];
-        c.vertical[i] = cam->vertical.e[i];
-        c.origin[i] = cam->origin.e[i];
-        c.u[i] = cam->u.e[i];
-        c.v[i] = cam->v.e[i];
-        c.w[i] = cam->w.e[i];
-    }
-    c.lens_radius = cam->lensRadius;
-    c.time0 = cam->time0;
-    c.time1 = cam->time1;
+    camera_block(*cam, out.view.camera);
     out.view.world = 0;
     out.view.n_prims = L.next_prim;
     out.view.n_media = L.n_media;

@@ -34,23 +34,26 @@ struct Built {
 /* pointer arrays live in the scene's arena like the nodes do */
 Hitable** ptr_array(size_t n) { return (Hitable**)rt::Arena::current()->allocate((n ? n : 1) * sizeof(Hitable*)); }
 
-/* a 256x128 RGB8 "planet": bands + a continent-like blob pattern, deterministic */
-std::vector<unsigned char>& procedural_map(int& w, int& h)
+/* a 256x128 RGB8 "planet": bands + a continent-like blob pattern, deterministic.  Built once, by the
+ * initialiser of a function-local static (thread-safe in C++11): rt_render builds the scene of every GPU in a
+ * thread of its own (driver/rt_main.cpp), so several threads can arrive here at once. */
+const std::vector<unsigned char>& procedural_map(int& w, int& h)
 {
-    static std::vector<unsigned char> img;
-    w = 256; h = 128;
-    if (img.empty()) {
-        img.resize((size_t)w * h * 3);
-        for (int j = 0; j < h; ++j)
-            for (int i = 0; i < w; ++i) {
+    static const std::vector<unsigned char> img = [] {
+        const int mw = 256, mh = 128;
+        std::vector<unsigned char> m((size_t)mw * mh * 3);
+        for (int j = 0; j < mh; ++j)
+            for (int i = 0; i < mw; ++i) {
                 unsigned v = (unsigned)(i * 7 + j * 13) ^ (unsigned)((i >> 3) * (j >> 2));
                 bool land = ((i / 16 + j / 16) % 3 == 0) ^ ((v & 31u) < 6u);
-                unsigned char* p = &img[3 * ((size_t)j * w + i)];
+                unsigned char* p = &m[3 * ((size_t)j * mw + i)];
                 p[0] = land ? (unsigned char)(60 + (v & 63u)) : (unsigned char)(10 + (j & 15));
                 p[1] = land ? (unsigned char)(120 + (v & 31u)) : (unsigned char)(40 + (i & 31));
                 p[2] = land ? (unsigned char)(40 + (v & 15u)) : (unsigned char)(150 + (v & 63u));
             }
-    }
+        return m;
+    }();
+    w = 256; h = 128;
     return img;
 }
 
@@ -120,9 +123,9 @@ Built random_spheres(int width, int height)
             } else list[i++] = new Sphere(centre, .2f, new Glass(1.5f));
         }
     int tw, th;
-    std::vector<unsigned char>& img = procedural_map(tw, th);
+    const std::vector<unsigned char>& img = procedural_map(tw, th);
     list[i++] = new Sphere(Vector3(-4, 1, 0), 1.0, new Glass(1.5f));
-    list[i++] = new Sphere(Vector3(0, 1, 0), 1.f, new Lambert(new ImageTexture(img.data(), tw, th)));
+    list[i++] = new Sphere(Vector3(0, 1, 0), 1.f, new Lambert(new ImageTexture(const_cast<unsigned char*>(img.data()), tw, th)));
     list[i++] = new Sphere(Vector3(4, 1, 0), 1.0, new Metal(new ConstantTexture(Vector3(0.7, 0.6, 0.5)), .1));
     Built b;
     b.world = new HitableList(list, i);
@@ -136,10 +139,10 @@ Built lit_sphere(int width, int height)
     Hitable** list = ptr_array(4);
     Texture* checker = new CheckerTexture(new ConstantTexture(Vector3(.2f, .3f, .1f)), new ConstantTexture(Vector3(.9f, .9f, .9f)));
     int tw, th;
-    std::vector<unsigned char>& img = procedural_map(tw, th);
+    const std::vector<unsigned char>& img = procedural_map(tw, th);
     int i = 0;
     list[i++] = new Sphere(Vector3(0.f, -1000.f, -1.f), 1000, new Lambert(checker));
-    list[i++] = new RotateY(new Sphere(Vector3(0, 1, 0), 1, new Lambert(new ImageTexture(img.data(), tw, th))), 0);
+    list[i++] = new RotateY(new Sphere(Vector3(0, 1, 0), 1, new Lambert(new ImageTexture(const_cast<unsigned char*>(img.data()), tw, th))), 0);
     list[i++] = new RotateY(new Sphere(Vector3(0, 7, 0), 2, new DiffuseLight(new ConstantTexture(Vector3(4, 4, 4)))), 120);
     Built b;
     b.world = new HitableList(list, i);
@@ -225,8 +228,8 @@ Built final_scene(int width, int height, int per_side)
     boundary = new Sphere(Vector3(0, 0, 0), 5000, new Glass(1.5f));
     list[l++] = new ConstantMedium(boundary, .0001, new ConstantTexture(Vector3(1, 1, 1)), &rng);
     int tw, th;
-    std::vector<unsigned char>& img = procedural_map(tw, th);
-    list[l++] = new Sphere(Vector3(400, 200, 400), 100, new Lambert(new ImageTexture(img.data(), tw, th)));
+    const std::vector<unsigned char>& img = procedural_map(tw, th);
+    list[l++] = new Sphere(Vector3(400, 200, 400), 100, new Lambert(new ImageTexture(const_cast<unsigned char*>(img.data()), tw, th)));
     const int ns = 1000;
     Hitable** cluster = ptr_array(ns);
     for (int j = 0; j < ns; j++) {
@@ -291,11 +294,11 @@ Built tri_mesh(int width, int height, int n_tris)
 Built kat(int width, int height)
 {
     int tw, th;
-    std::vector<unsigned char>& img = procedural_map(tw, th);
+    const std::vector<unsigned char>& img = procedural_map(tw, th);
     Texture* checker = new CheckerTexture(new ConstantTexture(Vector3(.2f, .3f, .1f)), new ConstantTexture(Vector3(.9f, .9f, .9f)));
     Material* lam = new Lambert(new ConstantTexture(Vector3(.5, .6, .7)));
     Material* lamc = new Lambert(checker);
-    Material* lami = new Lambert(new ImageTexture(img.data(), tw, th));
+    Material* lami = new Lambert(new ImageTexture(const_cast<unsigned char*>(img.data()), tw, th));
     Material* met = new Metal(new ConstantTexture(Vector3(.8, .7, .6)), .3f);
     Material* met2 = new Metal(new ConstantTexture(Vector3(.8, .8, .9)), 10.f);
     Material* gls = new Glass(1.5f);

@@ -300,6 +300,7 @@ int main(int argc, char** argv)
     std::cerr << "\nRendered in " << elapsed << " seconds to " << fileName << std::endl;
 
     /* mean, gamma 2 (main.cu:192-196), row flip + quantise (main.cu:668-697) */
+    /* outCol /= float(numSamples) in the reference IS a multiplication by the reciprocal (Vector3.cuh:157-164: k = 1.0f / t) */
     const float inv = 1.0f / float(numSamples);
     for (float& v : sum) { v *= inv; v = std::sqrt(v); }
     std::vector<uint8_t> pixels((size_t)width * height * 3);

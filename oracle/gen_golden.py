@@ -2,13 +2,17 @@
 """gen_golden.py — TEST INFRASTRUCTURE.  Writes the fixtures under tests/golden/.
 
 Run in the container that has /root/reference (after `make -C oracle` has produced
-oracle/_ref/libref.so).  Every expected value in the *_ref.npz files comes out of the REFERENCE's
-own hit()/scatter()/value() code, host-compiled by oracle/ref_driver.cpp; inputs are seeded numpy
-draws.  The converged images (images_*.npz) come from the CPU restatement oracle/rt_oracle.c,
+oracle/_ref/libref_geom.so and libref_shade.so).  Every expected value in the *_ref.npz files comes out of
+the REFERENCE's own code, host-compiled: hit() / value() / RotateY's constructor by oracle/ref_geom.cpp
+(no stand-in of any kind: these are the reference pin), scatter() / Metal's fuzz clamp by oracle/ref_shade.cpp
+(Material.cuh with curandState bound to rocRAND: a stand-in, so those vectors only cross-check the
+restatement).  Each fixture records which library made which arrays (`produced_by`, `*_produced_by`) and the
+tests assert it.  Inputs are seeded numpy draws.  The converged images (images_*.npz) come from the CPU restatement oracle/rt_oracle.c,
 because the reference's integrator (main.cu) cannot be built here.
 
 Each fixture stores a digest of the scene tables it was made from; tests refuse a stale fixture.
-  python oracle/gen_golden.py [--images]       (--images adds the slow converged renders)
+  python oracle/gen_golden.py [--images] [--full]   (--images adds the slow converged renders, --full the
+                                                     primary-hit maps of the full-size BASELINE scenes)
 """
 import argparse
 import os
@@ -47,6 +51,21 @@ def camera_rays(rng, cam, n):
     return np.concatenate([np.tile(org, (n, 1)), d, rng.random((n, 1)).astype(np.float32)], axis=1).astype(np.float32)
 
 
+def clean_front_face(flat, hits):
+    """Sphere / MovingSphere / Triangle::hit never write rec.bFrontFace (Sphere.cuh:25-56, Triangle.cuh:21-46) and
+    HitableList::hit hands back its uninitialised tempRec's byte (HitableList.cuh:19-28): stack garbage that changes from
+    build to build.  Only rects and boxes define it (setFaceNormal, Hitable.cuh:17-21); store 0 elsewhere."""
+    f = flat.contents
+    defined = np.zeros(f.n_prims + 1, bool)
+    for i in range(f.n_objects):
+        o = f.objects[i]
+        if o.prim_id >= 0 and o.type in (2, 3, 4, 5):
+            defined[o.prim_id] = True
+    ok = (hits["hit"] == 1) & defined[np.clip(hits["prim"], 0, f.n_prims)]
+    hits["front_face"] = np.where(ok, hits["front_face"], 0)
+    return hits
+
+
 GEOM_SCENES = [("kat", 0), ("cornell", 0), ("lit_sphere", 0), ("bvh_boxes", 0), ("random_spheres", 0),
                ("cornell_cluster", 0), ("final", 6), ("tri_mesh", 800)]
 W, H = 128, 72
@@ -57,6 +76,9 @@ def main():
     ap.add_argument("--images", nargs="*", default=None, metavar="SCENE",
                     help="also the slow converged renders (all of them, or only the scenes named)")
     ap.add_argument("--images-only", action="store_true", help="leave the vector fixtures as they are")
+    ap.add_argument("--full", action="store_true", help="also the 128x72 primary-hit maps of tri_mesh at 1,000,000 triangles and "
+                    "final at 100 x 100 boxes, from the reference's flat HitableList (minutes)")
+    ap.add_argument("--full-only", action="store_true", help="only those")
     args = ap.parse_args()
     b = entry.load_binding()
     o = entry.load_oracle()
@@ -67,6 +89,9 @@ def main():
     if args.images_only:
         make_images(args, b, orc)
         return
+    if args.full_only:
+        make_full(b, ref, orc)
+        return
     rng = np.random.default_rng(20261110)
 
     # ---- 1. per-object and whole-world closest hits -------------------------------------------
@@ -74,7 +99,7 @@ def main():
         sc = b.Scene(name, W, H, param)
         f = sc.flat.contents
         world = f.objects[f.world]
-        out = {"digest": scene_digest(sc.flat), "param": param, "width": W, "height": H}
+        out = {"digest": scene_digest(sc.flat), "param": param, "width": W, "height": H, "produced_by": ref.geom_id}
         # individual top-level objects (at most 16 of them), wrappers included
         kids = [world.child_begin + i for i in range(world.child_count)]
         picks = kids if len(kids) <= 16 else [kids[i] for i in sorted(rng.choice(len(kids), 16, replace=False))]
@@ -84,7 +109,7 @@ def main():
             if ob.type == 7:      # media are not buildable from the reference here
                 continue
             r = rays_at_box(rng, ob.bmin[:], ob.bmax[:], 384)
-            hits = ref.object_hit(sc.flat, oi, r, 0.001, FLT_MAX)
+            hits = clean_front_face(sc.flat, ref.object_hit(sc.flat, oi, r, 0.001, FLT_MAX))
             obj_ix.append(oi); obj_rays.append(r); obj_hits.append(hits)
         out["obj_index"] = np.array(obj_ix, np.int32)
         out["obj_rays"] = np.stack(obj_rays)
@@ -93,7 +118,7 @@ def main():
         out["win_rays"] = obj_rays[0]
         tm = np.median(obj_hits[0]["t"][obj_hits[0]["hit"] == 1]) if (obj_hits[0]["hit"] == 1).any() else 1.0
         out["win_range"] = np.array([0.25 * tm, 1.0 * tm], np.float32)
-        out["win_hits"] = ref.object_hit(sc.flat, picks[0], obj_rays[0], float(out["win_range"][0]), float(out["win_range"][1]))
+        out["win_hits"] = clean_front_face(sc.flat, ref.object_hit(sc.flat, picks[0], obj_rays[0], float(out["win_range"][0]), float(out["win_range"][1])))
         # whole world: camera rays + bounce-like rays leaving hit points
         cr = camera_rays(rng, f.camera, 3000)
         h0 = ref.object_hit(sc.flat, f.world, cr, 0.001, FLT_MAX)
@@ -103,7 +128,7 @@ def main():
         br[:, 3:6] = rng.normal(size=(len(br), 3)).astype(np.float32)
         wr = np.concatenate([cr, br]).astype(np.float32)
         out["world_rays"] = wr
-        out["world_hits"] = ref.object_hit(sc.flat, f.world, wr, 0.001, FLT_MAX)
+        out["world_hits"] = clean_front_face(sc.flat, ref.object_hit(sc.flat, f.world, wr, 0.001, FLT_MAX))
         # primary-hit map (pinhole-centre rays, the same ones rt_trace_primary builds)
         po, to = orc.trace_primary(sc.flat, W, H)           # restatement, to recover the rays' results
         cam = f.camera
@@ -123,7 +148,7 @@ def main():
     # ---- 2. materials and textures (scene "kat" carries one of each, "random_spheres" the glass) ----
     sc = b.Scene("kat", W, H)
     f = sc.flat.contents
-    out = {"digest": scene_digest(sc.flat)}
+    out = {"digest": scene_digest(sc.flat), "mat_produced_by": ref.shade_id, "tex_produced_by": ref.geom_id}
     n, XI = 512, 96
     mats, rays_in, recs, ps, res = [], [], [], [], []
     for mi in range(f.n_materials):
@@ -163,10 +188,43 @@ def main():
     sc_ = np.array([ref.rotate_sincos(float(a)) for a in angles], np.float32)
     fz = np.array([0.0, 0.3, 0.999, 1.0, 1.5, 10.0], np.float32)
     np.savez_compressed(os.path.join(GOLD, "misc_ref.npz"), rng_keys=np.array(keys, np.uint64), rng_uniforms=uni,
+                        rng_produced_by="rocRAND Philox4x32-10 of the image, through " + ref.shade_id,
+                        sincos_produced_by=ref.geom_id, fuzz_produced_by=ref.shade_id,
                         angles=angles, sincos=sc_, fuzz_in=fz, fuzz_out=np.array([ref.metal_fuzz(float(x)) for x in fz], np.float32))
     print("misc ok")
 
+    if args.full:
+        make_full(b, ref, orc)
     make_images(args, b, orc)
+
+
+def primary_rays(cam, w, h):
+    """the pinhole-centre ray of every pixel, built in fp32 exactly as rt_trace_primary / rto_trace_primary build it"""
+    jj, ii = np.mgrid[0:h, 0:w]
+    u = ((ii + np.float32(0.5)).astype(np.float32) / np.float32(w)).astype(np.float32)
+    v = ((jj + np.float32(0.5)).astype(np.float32) / np.float32(h)).astype(np.float32)
+    ll, hz, vt, og = (np.array(x[:], np.float32) for x in (cam.lower_left, cam.horizontal, cam.vertical, cam.origin))
+    d = ((ll + u[..., None] * hz).astype(np.float32) + v[..., None] * vt).astype(np.float32) - og
+    return np.concatenate([np.broadcast_to(og, d.shape), d.astype(np.float32), np.full(d.shape[:2] + (1,), cam.time0, np.float32)],
+                          axis=2).reshape(-1, 7)
+
+
+def make_full(b, ref, orc):
+    # ---- 5. the BASELINE target scenes at their real size: the reference's flat HitableList over every primitive ----
+    import time
+    for name, param in (("tri_mesh", 1000000), ("final", 100)):
+        sc = b.Scene(name, W, H, param)
+        f = sc.flat.contents
+        t0 = time.time()
+        ph = ref.object_hit(sc.flat, f.world, primary_rays(f.camera, W, H), 0.001, FLT_MAX, threads=os.cpu_count() or 1)
+        prim = ph["prim"].reshape(H, W)
+        t = np.where(ph["hit"] == 1, ph["t"], 0).astype(np.float32).reshape(H, W)
+        po, to = orc.trace_primary(sc.flat, W, H, use_bvh=True)          # the restatement's BVH traversal
+        differ = prim != po
+        print("%-10s param %7d: %d objects, reference flat list %.0f s; restatement (BVH) ids differ at %d pixels, t equal there: %s, t bit-equal: %s"
+              % (name, param, f.n_objects, time.time() - t0, int(differ.sum()), np.array_equal(t[differ], to[differ]), np.array_equal(t, to)))
+        np.savez_compressed(os.path.join(GOLD, "geom_%s_full_ref.npz" % name), digest=scene_digest(sc.flat), param=param, width=W, height=H,
+                            produced_by=ref.geom_id, primary_prim=prim, primary_t=t)
 
 
 def make_images(args, b, orc):

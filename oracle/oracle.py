@@ -1,5 +1,6 @@
 """ctypes loader for the CPU oracle (liboracle.so) and, where it was built, the host build of
-the reference's own headers (_ref/libref.so).  TEST INFRASTRUCTURE: imported only by tests/,
+the reference's own headers (_ref/libref_geom.so: geometry + textures, no stand-in; _ref/libref_shade.so:
+Material.cuh with its RNG names bound to rocRAND, a labelled stand-in).  TEST INFRASTRUCTURE: imported only by tests/,
 __graft_entry__.smoke() and bench.py's cpu_baseline leg."""
 import ctypes as C
 import hashlib
@@ -9,7 +10,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_PATH = os.path.join(_HERE, "liboracle.so")
-REF_PATH = os.path.join(_HERE, "_ref", "libref.so")
+REF_GEOM_PATH = os.path.join(_HERE, "_ref", "libref_geom.so")
+REF_SHADE_PATH = os.path.join(_HERE, "_ref", "libref_shade.so")
 
 HIT_DTYPE = np.dtype([("hit", "<i4"), ("prim", "<i4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4"),
                       ("p", "<f4", (3,)), ("n", "<f4", (3,)), ("front_face", "<i4"), ("material", "<i4")])
@@ -146,18 +148,43 @@ class Oracle(_Common):
 
 
 class Reference(_Common):
-    """The reference's own headers, host-compiled (only where /root/reference was present at build)."""
+    """The reference's own headers, host-compiled (only where /root/reference was present at build).
+    object_hit / texture_value / rotate_sincos come from libref_geom.so, which contains no stand-in;
+    scatter / uniforms / metal_fuzz come from libref_shade.so, whose curandState is rocRAND's (a stand-in)."""
 
-    def __init__(self, path=REF_PATH):
-        if not os.path.exists(path):
-            raise RuntimeError("%s missing (needs /root/reference): run `make -C oracle`" % path)
-        super().__init__(C.CDLL(path), "ref_")
+    def __init__(self, geom_path=REF_GEOM_PATH, shade_path=REF_SHADE_PATH):
+        for path in (geom_path, shade_path):
+            if not os.path.exists(path):
+                raise RuntimeError("%s missing (needs /root/reference): run `make -C oracle`" % path)
+        super().__init__(C.CDLL(geom_path), "ref_")
+        self.shade = C.CDLL(shade_path)
+        for lib in (self.lib, self.shade):
+            lib.ref_library_id.restype = C.c_char_p
+        self.geom_id = self.lib.ref_library_id().decode()
+        self.shade_id = self.shade.ref_library_id().decode()
+
+    def object_hit(self, flat, obj, rays, tmin, tmax, threads=1):
+        rays = _f32(rays)
+        out = np.zeros(rays.shape[0], dtype=HIT_DTYPE)
+        fn = self.lib.ref_object_hit_mt
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_int]
+        fn.restype = None
+        fn(C.cast(flat, C.c_void_p), obj, rays.shape[0], _ptr(rays), tmin, tmax, _ptr(out), threads)
+        return out
+
+    def uniforms(self, seed, pixel, sample, n):
+        out = np.zeros(n, dtype=np.float32)
+        fn = self.shade.ref_uniforms
+        fn.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+        fn.restype = None
+        fn(seed, pixel, sample, n, _ptr(out))
+        return out
 
     def scatter(self, flat, mat, ray_in, rec_in, seed, pixel_sample):
         ray_in, rec_in = _f32(ray_in), _f32(rec_in)
         ps = np.ascontiguousarray(pixel_sample, dtype=np.uint32)
         out = np.zeros(ray_in.shape[0], dtype=SCATTER_DTYPE)
-        fn = self._fn("scatter")
+        fn = self.shade.ref_scatter
         fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         fn.restype = None
         fn(C.cast(flat, C.c_void_p), mat, ray_in.shape[0], _ptr(ray_in), _ptr(rec_in), seed, _ptr(ps), _ptr(out))
@@ -172,7 +199,7 @@ class Reference(_Common):
         return s.value, c.value
 
     def metal_fuzz(self, f):
-        fn = self.lib.ref_metal_fuzz
+        fn = self.shade.ref_metal_fuzz
         fn.argtypes = [C.c_float]
         fn.restype = C.c_float
         return fn(f)
@@ -191,4 +218,4 @@ def scene_digest(flat):
 
 
 def reference_available():
-    return os.path.exists(REF_PATH)
+    return os.path.exists(REF_GEOM_PATH) and os.path.exists(REF_SHADE_PATH)

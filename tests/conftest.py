@@ -44,8 +44,16 @@ def load_golden(name):
     return np.load(os.path.join(GOLD, name))
 
 
+def made_by_reference_geometry(who):
+    """fixtures that pin parity must come from oracle/_ref/libref_geom.so, the host build of the reference's
+    geometry + texture headers that contains no stand-in (oracle/ref_geom.cpp)"""
+    who = str(who)
+    return who.startswith("libref_geom.so") and "no stand-in" in who
+
+
 def golden_scene(binding, oracle_mod, gold, name):
-    """the scene a fixture was made from; refuses a stale fixture"""
+    """the scene a fixture was made from; refuses a stale fixture and one not made by the reference's geometry build"""
+    assert made_by_reference_geometry(gold["produced_by"]), gold["produced_by"]
     sc = binding.Scene(name, int(gold["width"]), int(gold["height"]), int(gold["param"]))
     assert oracle_mod.scene_digest(sc.flat) == str(gold["digest"]), (
         "tests/golden fixture for %s is stale: re-run oracle/gen_golden.py where /root/reference exists" % name)

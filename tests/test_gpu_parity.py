@@ -65,6 +65,22 @@ def test_primary_hit_ids_and_t(binding, oracle_mod, gpu_ctx, name):
     assert (ep >= 0).any()
 
 
+@pytest.mark.parametrize("name", ["tri_mesh", "final"])
+def test_primary_hits_at_full_size_match_reference(binding, oracle_mod, gpu_ctx, name):
+    """north_star criterion 1 at the target scenes' REAL size: 1,000,000 triangles (BASELINE configs[3]) and the final
+    scene with 100 x 100 boxes (configs[4]) against the map the reference's flat HitableList gave (libref_geom.so)"""
+    g = load_golden("geom_%s_full_ref.npz" % name)
+    sc = golden_scene(binding, oracle_mod, g, name)
+    gpu_ctx.upload(sc)
+    prim, t = gpu_ctx.trace_primary(int(g["width"]), int(g["height"]))
+    ep, et = g["primary_prim"], g["primary_t"]
+    differ = prim != ep
+    assert np.array_equal(t[differ], et[differ]), "ids may only differ at exact ties"
+    assert differ.mean() < 0.01
+    assert np.allclose(t, et, rtol=1e-5, atol=0) and np.array_equal(t, et)
+    assert (ep >= 0).mean() > 0.4
+
+
 @pytest.mark.parametrize("name,param", [("kat", 0), ("cornell", 0), ("cornell_smoke", 0), ("random_spheres", 0),
                                         ("final", 8), ("tri_mesh", 4000), ("cornell_cluster", 0)])
 def test_closest_hit_matches_oracle_on_many_rays(binding, oracle, gpu_ctx, name, param):
