@@ -818,6 +818,12 @@ static hipError_t mega_launch(rt_ctx* c, int w, int h, int4 win, uint32_t s0, ui
     static const uint32_t variants[] = {RT_V_PLANAR, RT_V_PLANAR_MEDIA, RT_V_LIST, RT_V_BVH_TRI, RT_F_ALL, RT_V_NOISE};
     uint32_t pick = RT_V_NOISE;
     for (uint32_t v : variants) if ((c->features & ~v) == 0) { pick = v; break; }
+    /* test hook: RT_FORCE_VARIANT=list|all|noise runs a LARGER compiled variant than the scene needs (same results, by
+     * construction; tests/test_gpu_parity.py checks it: DESIGN.md 3.4).  Ignored when it does not cover the scene. */
+    if (const char* e = std::getenv("RT_FORCE_VARIANT")) {
+        const uint32_t want = !std::strcmp(e, "list") ? RT_V_LIST : !std::strcmp(e, "all") ? RT_F_ALL : !std::strcmp(e, "noise") ? RT_V_NOISE : 0u;
+        if (want && (c->features & ~want) == 0) pick = want;
+    }
 #define RT_LAUNCH(V, G) render_kernel<V, G><<<grid, RT_BLOCK, lds, c->stream>>>(c->ds, w, h, win, s0, s1, k0, k1, max_depth, accum, c->d_counters, per, partial, groups, tile_step)
 #define RT_LAUNCH_BG(V) { if (background == RT_BG_BLACK) RT_LAUNCH(V, RT_BG_BLACK); else RT_LAUNCH(V, RT_BG_SKY); }
     switch (pick) {
@@ -879,7 +885,10 @@ extern "C" int rt_render_accumulate_window(rt_ctx* c, int w, int h, int x0, int 
     c->last_integrator = wavefront ? RT_INTEGRATOR_WAVEFRONT : RT_INTEGRATOR_MEGAKERNEL;
     if (wavefront) {
         /* the first variant that covers the scene's features */
-        int wrc = (c->features & ~RT_V_BVH_TRI) == 0 ? wf_run<RT_V_BVH_TRI>(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum)
+        const char* force = std::getenv("RT_FORCE_VARIANT");          /* test hook, as in mega_launch */
+        const bool force_all = force && (!std::strcmp(force, "all") || !std::strcmp(force, "list")) && (c->features & ~RT_F_ALL) == 0;
+        int wrc = force_all ? wf_run<RT_F_ALL>(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum)
+                  : (c->features & ~RT_V_BVH_TRI) == 0 ? wf_run<RT_V_BVH_TRI>(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum)
                   : (c->features & ~RT_V_NOTRI) == 0 ? wf_run<RT_V_NOTRI>(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum)
                   : (c->features & ~RT_F_ALL) == 0   ? wf_run<RT_F_ALL>(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum)
                                                      : wf_run<RT_V_NOISE>(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum);

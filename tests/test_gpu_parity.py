@@ -152,6 +152,30 @@ def test_render_equals_oracle_sample_for_sample(binding, oracle, gpu_ctx, name, 
     assert exp.sum() > 0
 
 
+@pytest.mark.parametrize("variant", ["list", "all"])
+@pytest.mark.parametrize("integrator", INTEGRATORS)
+@pytest.mark.parametrize("name", ["cornell", "cornell_smoke"])
+def test_larger_kernel_variants_trace_the_same_paths(binding, oracle, gpu_ctx, monkeypatch, name, integrator, variant):
+    """an early all-features kernel (128 VGPRs + ~100 SGPR spills) once returned wrong rect misses on the
+    Cornell box.  Dispatch normally picks the smallest compiled variant, so the Cornell scenes never ran under the big
+    ones; RT_FORCE_VARIANT makes them: RT_V_LIST and RT_F_ALL must give the oracle's image sample for sample, and the
+    bits of the variant the scene normally runs on."""
+    import torch
+    W, H, spp = 64, 48, 8
+    sc = binding.Scene(name, W, H)
+    gpu_ctx.upload(sc)
+    monkeypatch.delenv("RT_FORCE_VARIANT", raising=False)
+    usual = render_gpu(gpu_ctx, binding, sc, W, H, 0, spp, 419, integrator=integrator)
+    monkeypatch.setenv("RT_FORCE_VARIANT", variant)
+    forced = render_gpu(gpu_ctx, binding, sc, W, H, 0, spp, 419, integrator=integrator)
+    monkeypatch.delenv("RT_FORCE_VARIANT", raising=False)
+    exp, _ = oracle.render(sc.flat, W, H, 0, spp, 419, 100, sc.background, threads=8)
+    got = forced.cpu().numpy().reshape(H, W, 3)
+    bad = np.any(np.abs(got - exp) > 1e-4 * (1 + np.abs(exp)), axis=2)
+    assert bad.mean() <= 0.005, "%d of %d pixels differ from the oracle under RT_FORCE_VARIANT=%s" % (bad.sum(), bad.size, variant)
+    assert torch.equal(forced, usual), "variant %s and the scene's own variant differ in %d floats" % (variant, int((forced != usual).sum()))
+
+
 @pytest.mark.parametrize("integrator", INTEGRATORS)
 def test_sky_integrator_and_depth_limit(binding, oracle, gpu_ctx, integrator):
     """colourUnlit (main.cu:73-100) on a scene with emitters, and max_depth 0/1/3"""
