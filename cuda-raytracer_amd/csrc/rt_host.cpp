@@ -66,6 +66,12 @@ bool rt_validate_scene(const rt_flat_scene* s, std::string& why, int* bvh_depth)
     }
     for (int i = 0; i < s->n_ops; ++i)
         if (s->ops[i].type != RT_OP_TRANSLATE && s->ops[i].type != RT_OP_ROTATE_Y) return bad("unknown transform op");
+    /* device leaf references are ~((first item << 4) | (count - 1)) in an int32 (rt_pack_bvh, rt_pack_bvh4): the first
+     * item needs to stay below 2^27 or the reference turns non-negative and reads as an interior node */
+    if (s->n_bvh_items >= (1 << 27)) return bad("more than 2^27 - 1 BVH items");
+    /* the scan program and rebuild() treat the world list's frame as the world frame: a wrapper chain on the world
+     * object itself would be traversed in one frame and shaded in another (rt::lower never produces one) */
+    if (s->objects[s->world].op_count != 0) return bad("the world object carries a transform chain");
     for (int i = 0; i < s->n_bvh_items; ++i) {
         int oi = s->bvh_items[i];
         if (oi < 0 || oi >= s->n_objects) return bad("BVH item out of range");

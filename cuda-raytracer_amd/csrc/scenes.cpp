@@ -243,6 +243,59 @@ Built final_scene(int width, int height, int per_side)
     return b;
 }
 
+/* The reference's seventh scene (main.cu:454-524), its own variation of the final scene: ground boxes whose WIDTH is
+ * random as well (:473, so the grid overlaps and gaps), no ceiling light but a green light rect far below the world at
+ * y = -3000 (:491) and a white light sphere of radius 500 at y = 1500 (:509).  The box sizes come from a COPY of the
+ * scene's RNG state (`localRandState`, :456) and the cluster's sphere centres from the state itself (:503), so the two
+ * sequences start at the same uniforms: kept.  param = boxes per side (0 -> 20). */
+Built final_custom(int width, int height, int per_side)
+{
+    curandState rng;                      /* RND draws from this one: the reference's localRandState copy */
+    curand_init(419, 0, 0, &rng);
+    curandState shared = rng;             /* *randState, untouched by the box loop */
+    const int nb = per_side > 0 ? per_side : 20;
+    Hitable** boxes = ptr_array((size_t)nb * nb);
+    Material* white = new Lambert(new ConstantTexture(Vector3(.73, .73, .73)));
+    Material* ground = new Lambert(new ConstantTexture(Vector3(.48, .83, .53)));
+    int n = 0;
+    for (float i = 0; i < nb; i++)
+        for (float j = 0; j < nb; j++) {
+            const float w = 100 * (RND + .01f);
+            const float x0 = -1000 + i * w, z0 = -1000 + j * w;
+            const float y1 = 100 * (RND + 0.01f);
+            boxes[n++] = new Box(Vector3(x0, 0, z0), Vector3(x0 + w, y1, z0 + w), ground);
+        }
+    Hitable** list = ptr_array(16);
+    int l = 0;
+    list[l++] = new BvhNode(boxes, n, 0, 200, &shared);
+    list[l++] = new XZRect(-1000, 1000, -1000, 1000, -3000,
+                           new DiffuseLight(new ConstantTexture(Vector3(2 * (22 / 255.f), 2 * (217 / 255.f), 2 * (25 / 255.f)))));
+    const Vector3 centre(400, 400, 200);
+    list[l++] = new MovingSphere(centre, centre + Vector3(30, 0, 0), 0, 1, 50, new Lambert(new ConstantTexture(Vector3(.7, .3, .1))));
+    list[l++] = new Sphere(Vector3(260, 150, 45), 50, new Glass(1.5));
+    list[l++] = new Sphere(Vector3(0, 150, 145), 50, new Metal(new ConstantTexture(Vector3(.8, .8, .9)), 10.f));
+    Hitable* boundary = new Sphere(Vector3(360, 150, 145), 70, new Glass(1.5));
+    list[l++] = boundary;
+    list[l++] = new ConstantMedium(boundary, .2, new ConstantTexture(Vector3(.2, .4, .9)), &shared);
+    boundary = new Sphere(Vector3(0, 0, 0), 5000, new Glass(1.5f));
+    list[l++] = new ConstantMedium(boundary, .0001, new ConstantTexture(Vector3(1, 1, 1)), &shared);
+    int tw, th;
+    const std::vector<unsigned char>& img = procedural_map(tw, th);
+    list[l++] = new Sphere(Vector3(400, 200, 400), 100, new Lambert(new ImageTexture(const_cast<unsigned char*>(img.data()), tw, th)));
+    const int ns = 1000;
+    Hitable** cluster = ptr_array(ns);
+    for (int j = 0; j < ns; j++) {
+        const float x = 165 * curand_uniform(&shared), y = 165 * curand_uniform(&shared), z = 165 * curand_uniform(&shared);
+        cluster[j] = new Sphere(Vector3(x, y, z), 10, white);
+    }
+    list[l++] = new Translate(new RotateY(new BvhNode(cluster, ns, 0.f, 1.f, &shared), 15), Vector3(-100, 270, 395));
+    list[l++] = new Sphere(Vector3(0, 1500, 0), 500, new DiffuseLight(new ConstantTexture(Vector3(1, 1, 1))));
+    Built b;
+    b.world = new HitableList(list, l);
+    b.cam = look(Vector3(478, 278, -600), Vector3(278, 278, 0), 40.f, width, height, 0.f, 10.f);
+    return b;
+}
+
 /* Synthetic mesh: a displaced nx x nz grid (two Lambert triangles per cell) over [-500,500]^2,
  * heights from an LCG (seed 1), under a large emissive rect. */
 Built tri_mesh(int width, int height, int n_tris)
@@ -361,6 +414,7 @@ Built build_named(const std::string& name, int width, int height, int param, boo
     if (name == "bvh_boxes") return bvh_boxes(width, height);
     if (name == "cornell_cluster") return cornell_cluster(width, height);
     if (name == "final") return final_scene(width, height, param);
+    if (name == "final_custom") return final_custom(width, height, param);
     if (name == "tri_mesh") return tri_mesh(width, height, param);
     if (name == "kat") return kat(width, height);
     known = false;

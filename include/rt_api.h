@@ -67,6 +67,8 @@ const char* rt_last_error(void);
  *   "bvh_boxes"       BvhNode of boxes + light sphere  (main.cu:309-352)
  *   "cornell_cluster" glass box + instanced sphere BVH (main.cu:417-451)
  *   "final"           Next-Week final scene; param = boxes per side (0 -> 20)   (main.cu:355-414)
+ *   "final_custom"    the reference's own final-scene variant: random box widths, light sphere + green
+ *                     light rect below; param = boxes per side (0 -> 20)                 (main.cu:454-524)
  *   "tri_mesh"        synthetic triangle mesh + light; param = triangle count (0 -> 1,000,000)
  *   "kat"             one of every primitive / wrapper, for parity tests
  * C++ callers with their own scene functions use rt::lower() (csrc/lower.h) and

@@ -67,7 +67,7 @@ def clean_front_face(flat, hits):
 
 
 GEOM_SCENES = [("kat", 0), ("cornell", 0), ("lit_sphere", 0), ("bvh_boxes", 0), ("random_spheres", 0),
-               ("cornell_cluster", 0), ("final", 6), ("tri_mesh", 800)]
+               ("cornell_cluster", 0), ("final", 6), ("tri_mesh", 800), ("final_custom", 6)]
 W, H = 128, 72
 
 

@@ -60,7 +60,7 @@ def golden_scene(binding, oracle_mod, gold, name):
     return sc
 
 
-GEOM_SCENES = ["kat", "cornell", "lit_sphere", "bvh_boxes", "random_spheres", "cornell_cluster", "final", "tri_mesh"]
+GEOM_SCENES = ["kat", "cornell", "lit_sphere", "bvh_boxes", "random_spheres", "cornell_cluster", "final", "tri_mesh", "final_custom"]
 RECT_TYPES = (2, 3, 4, 5)       # front_face is only defined by the reference for rects and boxes
 MOVING_SPHERE = 1               # u,v are left stale by the reference (Sphere.cuh:91-120)
 

@@ -91,6 +91,43 @@ def test_from_flat_round_trip_and_validation(binding, oracle_mod):
     h3 = C.c_void_p()
     assert binding.lib().rt_scene_from_flat(sc.flat, C.byref(h3)) < 0
     f.bvh_items[0] = keep
+    # a wrapper chain on the world object itself: the scan would run in one frame and the shading in another
+    world = f.objects[f.world]
+    keep = (world.op_begin, world.op_count)
+    world.op_begin, world.op_count = 0, 1
+    h4 = C.c_void_p()
+    assert binding.lib().rt_scene_from_flat(sc.flat, C.byref(h4)) < 0
+    assert b"world object carries a transform chain" in binding.lib().rt_last_error()
+    world.op_begin, world.op_count = keep
+    # more BVH items than a 27-bit leaf reference can address (the count alone is checked before any item is read)
+    keep = f.n_bvh_items
+    f.n_bvh_items = 1 << 27
+    h5 = C.c_void_p()
+    assert binding.lib().rt_scene_from_flat(sc.flat, C.byref(h5)) < 0
+    assert b"2^27" in binding.lib().rt_last_error()
+    f.n_bvh_items = keep
+    assert binding.lib().rt_scene_from_flat(sc.flat, C.byref(h5)) == 0
+    binding.lib().rt_scene_destroy(h5)
+
+
+def test_builtin_scenes_are_built_once_per_process_and_thread_safe(binding, oracle_mod):
+    """rt_render builds the scene of every GPU in a thread of its own; the shared procedural texture map must come out
+    the same in all of them (it used to be filled lazily without synchronisation)"""
+    import threading
+    digests, errors = [], []
+
+    def build():
+        try:
+            sc = binding.Scene("final", 64, 48, 6)
+            digests.append(oracle_mod.scene_digest(sc.flat))
+        except Exception as e:       # noqa: BLE001
+            errors.append(e)
+    threads = [threading.Thread(target=build) for _ in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors and len(set(digests)) == 1 and len(digests) == 8
 
 
 def test_headers_are_plain_c(tmp_path):

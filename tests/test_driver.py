@@ -109,3 +109,47 @@ def test_checkpoint_and_resume(tmp_path):
     r = run_driver(sc, stdin, "cornell_smoke", "--chunk", "2", "--scatter")
     assert r.returncode == 0, r.stderr
     assert np.array_equal(read_ppm(sc / "output" / "singleGPUTesting.ppm"), a)
+
+
+DROPIN = os.path.join(ROOT, "cuda-raytracer_amd", "rt_dropin")
+
+
+def test_dropin_caller_is_built():
+    """driver/dropin_main.cpp calls gpuRender(w, h, spp, tx, ty, gpuId) the way main.cu:652-704 does and includes the
+    drop-in headers by the reference's names; it must compile and link against the library"""
+    assert os.path.exists(DROPIN), "build it with make -C cuda-raytracer_amd (or __graft_entry__.build())"
+
+
+@pytest.mark.gpu
+def test_gpu_render_drop_in(binding, gpu_ctx, tmp_path):
+    """gpuRender's buffer contract (main.cu:553-620): gamma-2 Vector3 frame, row 0 = bottom, gpuId 0 / 1 = column halves
+    stitched by the caller, other ids = full frame; equal to what the C ABI renders for the same seed and samples"""
+    import torch
+    W, H, spp = 51, 36, 8                       # odd width: the halves overlap in the middle column (main.cu:132,153)
+    frames = {}
+    for gpus in (1, 2):
+        r = subprocess.run([DROPIN, str(W), str(H), str(spp), str(gpus)], capture_output=True, text=True, cwd=str(tmp_path), timeout=120)
+        assert r.returncode == 0, r.stderr
+        frames[gpus] = np.fromfile(tmp_path / "output" / "dropin.f32", dtype=np.float32).reshape(H, W, 3)
+    sc = binding.Scene("cornell", W, H)
+    gpu_ctx.upload(sc)
+    acc = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    gpu_ctx.render_accumulate(acc, W, H, 0, spp, 419, 100, sc.background)
+    rgb = gpu_ctx.resolve(acc, W, H, spp, gamma=True)
+    gpu_ctx.synchronize()
+    exp = rgb.cpu().numpy().reshape(H, W, 3)
+    assert np.array_equal(frames[1], exp)
+    assert np.array_equal(frames[2], exp)       # a window traces the paths the full frame traces for its pixels
+    png = decode_png(open(tmp_path / "output" / "dropin.png", "rb").read())
+    assert np.array_equal(png, np.clip((255.99 * exp.astype(np.float64)).astype(np.int64), 0, 255).astype(np.uint8)[::-1])
+    # a user's scene function in the reference's form, through gpuRenderUseScene
+    got = {}
+    for gpus in (1, 2):
+        r = subprocess.run([DROPIN, str(W), str(H), "4", str(gpus), "user"], capture_output=True, text=True, cwd=str(tmp_path), timeout=120)
+        assert r.returncode == 0, r.stderr
+        got[gpus] = np.fromfile(tmp_path / "output" / "dropin.f32", dtype=np.float32).reshape(H, W, 3)
+    assert np.isfinite(got[1]).all() and got[1].max() > 0 and not np.array_equal(got[1], frames[1][:, :, :])
+    assert np.array_equal(got[1], got[2])
+    r = subprocess.run([DROPIN, "0", "8", "1", "1"], capture_output=True, text=True, cwd=str(tmp_path), timeout=60)
+    assert r.returncode == 99                   # main.cu:33-44

@@ -82,7 +82,7 @@ def test_primary_hits_at_full_size_match_reference(binding, oracle_mod, gpu_ctx,
 
 
 @pytest.mark.parametrize("name,param", [("kat", 0), ("cornell", 0), ("cornell_smoke", 0), ("random_spheres", 0),
-                                        ("final", 8), ("tri_mesh", 4000), ("cornell_cluster", 0)])
+                                        ("final", 8), ("tri_mesh", 4000), ("cornell_cluster", 0), ("final_custom", 0)])
 def test_closest_hit_matches_oracle_on_many_rays(binding, oracle, gpu_ctx, name, param):
     """60k camera + bounce rays per scene, incl. bounded (tmin,tmax) windows"""
     W, H = 96, 64
@@ -133,7 +133,8 @@ def render_gpu(ctx, binding, sc, W, H, s0, s1, seed, depth=100, bg=None, integra
                                                ("kat", 0, 64, 48, 6), ("random_spheres", 0, 48, 32, 4),
                                                ("lit_sphere", 0, 64, 48, 8), ("cornell_cluster", 0, 48, 32, 4),
                                                ("tri_mesh", 4000, 48, 32, 4), ("final", 8, 48, 32, 4),
-                                               ("cornell", 0, 37, 23, 5), ("perlin", 0, 64, 48, 8)])
+                                               ("cornell", 0, 37, 23, 5), ("perlin", 0, 64, 48, 8),
+                                               ("final_custom", 8, 48, 32, 4)])
 @pytest.mark.parametrize("integrator", INTEGRATORS)
 def test_render_equals_oracle_sample_for_sample(binding, oracle, gpu_ctx, name, param, W, H, spp, integrator):
     """same (seed, pixel, sample) -> same path: the accumulation buffers agree pixel for pixel, up to the rare
@@ -505,3 +506,21 @@ def test_wavefront_pools_do_not_change_the_image(binding, gpu_ctx, monkeypatch):
         assert float(images[0].sum()) > 0
         for im, r in zip(images[1:], rays[1:]):
             assert torch.equal(im, images[0]) and r == rays[0]
+
+
+def test_wavefront_failure_leaves_the_context_usable(binding, gpu_ctx, monkeypatch):
+    """the wavefront loop's error exits (a queue that does not drain, a failing HIP call) wait for every pool's stream
+    before returning: forced here with RT_WF_DEBUG_MAX_ITERS=0, after which the same context renders as if nothing
+    had happened"""
+    import torch
+    W, H, spp = 64, 48, 6
+    sc = binding.Scene("final", W, H, 8)
+    gpu_ctx.upload(sc)
+    good = render_gpu(gpu_ctx, binding, sc, W, H, 0, spp, 5, integrator="wavefront")
+    monkeypatch.setenv("RT_WF_DEBUG_MAX_ITERS", "0")
+    with pytest.raises(binding.RtError) as e:
+        render_gpu(gpu_ctx, binding, sc, W, H, 0, spp, 5, integrator="wavefront")
+    assert "did not drain" in str(e.value)
+    monkeypatch.delenv("RT_WF_DEBUG_MAX_ITERS")
+    again = render_gpu(gpu_ctx, binding, sc, W, H, 0, spp, 5, integrator="wavefront")
+    assert torch.equal(again, good)

@@ -1,13 +1,20 @@
-"""Summarise a rocprofv3 --pmc counter_collection.csv for the render kernel (development aid)."""
-import csv, glob, sys
+"""Sum (and average) the rows of rocprofv3 --pmc counter_collection.csv files per kernel and counter (development aid).
+  python tools/pmc_summary.py DIR [kernel-name-substring ...]     default substrings: wf_ render_kernel"""
+import collections
+import csv
+import glob
+import sys
+
 d = sys.argv[1]
-rows = []
+want = sys.argv[2:] or ["wf_", "render_kernel"]
+acc = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-    rows += list(csv.DictReader(open(f)))
-acc = {}
-for r in rows:
-    if "render_kernel" in r["Kernel_Name"]:
-        acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-for k in sorted(acc):
-    v = acc[k]
-    print("%-28s n=%d mean=%.6g" % (k, len(v), sum(v) / len(v)))
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0][:48]
+        if not any(s in k for s in want):
+            continue
+        a = acc[(k, r["Counter_Name"])]
+        a[0] += float(r["Counter_Value"])
+        a[1] += 1
+for (k, c), (v, n) in sorted(acc.items()):
+    print("%-50s %-24s sum=%.6g launches=%d mean=%.6g" % (k, c, v, n, v / n))

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
-SCENES = ["kat", "cornell", "lit_sphere", "bvh_boxes", "random_spheres", "cornell_cluster", "final", "tri_mesh"]
+SCENES = ["kat", "cornell", "lit_sphere", "bvh_boxes", "random_spheres", "cornell_cluster", "final", "tri_mesh", "final_custom"]
 
 
 def main():
