@@ -28,6 +28,7 @@ F_RECT, F_SPHERE, F_TRI, F_NODE, F_ROT, F_TRANS = 15.0, 30.0, 105.0, 50.0, 12.0,
 F_SHADE, F_SPHERE_ITER, F_PHILOX = 60.0, 20.0, 100.0
 PEAK_VALU_TFLOPS = 157.3   # MI355X fp32 vector peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0      # HBM3E spec peak
+L2_MISS_REQUESTS_PEAK = 58.0   # G random 64-B / 128-B row requests per second that leave the L2s, measured (profiles/r02_gather_rates.jsonl)
 
 WORKLOADS = {
     # name: (scene, param, width, height, spp)
@@ -69,7 +70,9 @@ def cpu_baseline(binding, oracle_mod, scene_name, param, background, use_bvh, bu
     W = H = 128
     scene = binding.Scene(scene_name, W, H, param)
     orc = oracle_mod.Oracle()
-    threads = max(1, min(16, os.cpu_count() or 1))
+    # all the host cores this job may use: the scheduler's share where it sets one, and never more than the 16 a one-GPU
+    # box grants (its os.cpu_count() shows the whole machine); the line states what was used and what was visible
+    threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
     import numpy as np
     acc = np.zeros((H, W, 3), dtype=np.float32)
     tot = None
@@ -93,7 +96,7 @@ def cpu_baseline(binding, oracle_mod, scene_name, param, background, use_bvh, bu
     return {
         "value": tot.rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
         "sample": "%s at %dx%d, %d spp, depth 100, %d threads, %.1f s" % (scene_name, W, H, s, threads, dt),
-        "value_1core": st1.rays / dt1 / 1e6,
+        "value_1core": st1.rays / dt1 / 1e6, "cores_visible": os.cpu_count(), "cores_cap": 16,
     }, tot
 
 
@@ -234,12 +237,25 @@ def main():
         else:
             out["cpu_baseline"] = None
         # roofline of the dominant kernel, duration from HIP events recorded on its own stream inside the library.
-        # megakernel: render_kernel is the launch; wavefront: the event pair spans the whole intersect/logic loop
-        # (profiles/ has the per-kernel split: wf_intersect is ~85 % of it).
+        # megakernel: render_kernel is the launch, bound by VALU issue (its tables sit in the scalar cache).
+        # wavefront: the event pair spans the whole intersect/logic loop (the pools' kernels overlap, so per-kernel
+        # durations of a trace add up to more than the call).  What bounds it is the rate at which the L2s can send
+        # MISSES to the fabric: tools/ubench/gather.hip measures 58 G random row requests/s chip-wide on this part for
+        # 64-B and for 128-B rows alike, from a 110 MB table (Infinity Cache) and from a 1 GB one (HBM) alike.  The
+        # intersect kernel fetches one 128-B row per 4-wide node step and one 64-B row per leaf primitive (counted by
+        # the diagnostic build, tools/stamps.py); the L2 hit rate comes from the committed PMC pass.  The algorithmic
+        # HBM-bytes fraction SURVEY 8(d) defines is carried under "hbm_algorithmic"; it is not what binds.
         rays_per_launch = rays / world / max(1, c.render_launches)
         kname = "wf_intersect_kernel + wf_logic_kernel loop" if wavefront else "render_kernel"
-        roof = {"bound": "hbm" if wavefront else "valu", "kernel": kname, "kernel_ms": kernel_ms,
-                "peak": PEAK_HBM_GBS if wavefront else PEAK_VALU_TFLOPS, "unit": "GB/s" if wavefront else "TFLOP/s",
+        pm = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(tpath):
+            try:
+                pm = json.load(open(tpath)).get(out["config"]["workload"])
+            except Exception:
+                pm = None
+        roof = {"bound": "l2-miss-requests" if wavefront else "valu", "kernel": kname, "kernel_ms": kernel_ms,
+                "peak": L2_MISS_REQUESTS_PEAK if wavefront else PEAK_VALU_TFLOPS, "unit": "Grequests/s" if wavefront else "TFLOP/s",
                 "achieved": None, "frac": None, "traffic": None}
         if base_stats is not None and kernel_ms > 0:
             fpr = flops_per_ray(base_stats)
@@ -247,23 +263,27 @@ def main():
             ach_f = rays_per_launch * fpr / (kernel_ms * 1e-3) / 1e12
             ach_b = rays_per_launch * bpr / (kernel_ms * 1e-3) / 1e9
             if wavefront:
-                roof.update({"achieved": ach_b, "frac": ach_b / PEAK_HBM_GBS})
+                rows = (pm or {}).get("rows_per_ray")
+                hit = (pm or {}).get("l2_hit_rate")
+                if rows and hit is not None:
+                    per_ray = rows["node4_128B"] + rows["leaf_64B"] + rows["state_64B"]
+                    ach = rays_per_launch * per_ray * (1.0 - hit) / (kernel_ms * 1e-3) / 1e9
+                    roof.update({"achieved": ach, "frac": ach / L2_MISS_REQUESTS_PEAK, "row_requests_per_ray": per_ray, "l2_hit_rate": hit})
+                roof["hbm_algorithmic"] = {"bytes_per_ray": bpr, "achieved_GBs": ach_b, "peak_GBs": PEAK_HBM_GBS, "frac": ach_b / PEAK_HBM_GBS,
+                                           "note": "SURVEY 8(d) formula; the BVH sits in the Infinity Cache, HBM bandwidth does not bind"}
+                roof["l3_gather_peak"] = {"Grequests_per_s": L2_MISS_REQUESTS_PEAK, "TB_per_s_at_128B_rows": 6.6, "TB_per_s_at_64B_rows": 3.7,
+                                          "source": "profiles/r02_gather_rates.jsonl (tools/ubench/gather.hip)"}
             else:
                 roof.update({"achieved": ach_f, "frac": ach_f / PEAK_VALU_TFLOPS})
-            roof.update({"flops_per_ray": fpr, "bytes_per_ray": bpr,
-                         "valu_peak_TFLOPs": PEAK_VALU_TFLOPS, "valu_achieved_TFLOPs": ach_f, "valu_frac": ach_f / PEAK_VALU_TFLOPS,
-                         "hbm_peak_GBs": PEAK_HBM_GBS, "hbm_achieved_GBs": ach_b, "hbm_frac": ach_b / PEAK_HBM_GBS})
+            roof.update({"flops_per_ray": fpr, "valu_peak_TFLOPs": PEAK_VALU_TFLOPS, "valu_achieved_TFLOPs": ach_f, "valu_frac": ach_f / PEAK_VALU_TFLOPS})
+            if not wavefront:
+                roof.update({"bytes_per_ray": bpr, "hbm_peak_GBs": PEAK_HBM_GBS, "hbm_achieved_GBs": ach_b, "hbm_frac": ach_b / PEAK_HBM_GBS})
         # counters cannot be read in-process: the per-call HBM bytes and the PMC-derived shares come from the
-        # committed rocprofv3 passes of this same command (tools/prof_round.sh -> profiles/pmc_summary.json)
-        tpath = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(tpath):
-            try:
-                pm = json.load(open(tpath)).get(out["config"]["workload"])
-                if pm:
-                    roof["traffic"] = pm.get("traffic_bytes")
-                    roof["pmc"] = {k: v for k, v in pm.items() if k != "traffic_bytes"}
-            except Exception:
-                pass
+        # committed rocprofv3 passes of this same command (tools/prof_round.sh -> profiles/pmc_summary.json), which
+        # carry the commit they were taken at: after a kernel change they describe THAT build until the passes are re-run
+        if pm:
+            roof["traffic"] = pm.get("traffic_bytes")
+            roof["pmc"] = {k: v for k, v in pm.items() if k != "traffic_bytes"}
         out["roofline"] = roof
         return out
 

@@ -232,25 +232,30 @@ def test_virtual_shards_reduce_to_the_single_gpu_image(binding, gpu_ctx):
 
 @pytest.mark.parametrize("name", ["cornell", "cornell_smoke", "random_spheres", "lit_sphere", "final"])
 def test_converged_image_rmse(binding, oracle_mod, gpu_ctx, name):
-    """north_star criterion 2: linear RMSE <= 1e-3 against the oracle's converged image (different seed)"""
+    """north_star criterion 2: linear RMSE <= 1e-3 against the oracle's converged 64 x 64 image, rendered with another
+    seed.  The goldens' sample counts follow each scene's measured per-pixel variance (oracle/gen_golden.py
+    IMAGE_SCENES: golden noise <= 6e-4), the GPU renders 4 x as many (<= 3e-4); both sides sum chunks of samples in
+    float64 so that half a million fp32 additions do not eat the small terms."""
     import os
+    import torch
     from conftest import GOLD
     path = os.path.join(GOLD, "image_%s_oracle.npz" % name)
-    if not os.path.exists(path):
-        pytest.skip("no converged golden for " + name)
     g = np.load(path)
     W, H = int(g["width"]), int(g["height"])
+    assert (W, H) == (64, 64)
     sc = binding.Scene(name, W, H, 8 if name == "final" else 0)      # final: the mini scene of the golden
     assert oracle_mod.scene_digest(sc.flat) == str(g["digest"])
     gpu_ctx.upload(sc)
     spp = 4 * int(g["spp"])
     # the wavefront form runs thousands of sample streams of the 64x64 frame side by side; the megakernel
     # would occupy 16 workgroups for minutes.  test_integrators_agree ties the two together.
-    acc = render_gpu(gpu_ctx, binding, sc, W, H, 0, spp, 99991, integrator="wavefront")
-    img = (acc.cpu().numpy().reshape(H, W, 3) / np.float32(spp))
+    total = torch.zeros(H * W * 3, dtype=torch.float64, device="cuda")
+    chunk = 131072
+    for s0 in range(0, spp, chunk):
+        total += render_gpu(gpu_ctx, binding, sc, W, H, s0, min(spp, s0 + chunk), 99991, integrator="wavefront").double()
+    img = (total / spp).float().cpu().numpy().reshape(H, W, 3)
     rmse = float(np.sqrt(np.mean((img - g["image"]) ** 2)))
-    limit = 1e-3 if name in ("cornell", "cornell_smoke") else 4e-3   # goldens of the slow scenes have fewer spp
-    assert rmse <= limit, rmse
+    assert rmse <= 1e-3, rmse
 
 
 @pytest.mark.parametrize("name,param", [("cornell", 0), ("cornell_smoke", 0), ("final", 8), ("tri_mesh", 20000), ("perlin", 0)])
