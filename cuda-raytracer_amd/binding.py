@@ -69,6 +69,9 @@ class RtCounters(C.Structure):
                 ("last_render_ms", C.c_double), ("render_launches", C.c_uint32), ("last_integrator", C.c_uint32)]
 
 
+# numpy dtype with the layout of rt_scatter_record / rto_scatter_out (60 bytes)
+SCATTER_DTYPE = [("ok", "<i4"), ("attenuation", "<f4", (3,)), ("origin", "<f4", (3,)), ("direction", "<f4", (3,)),
+                 ("time", "<f4"), ("emitted", "<f4", (3,)), ("draws", "<u4")]
 # numpy dtype with the layout of rt_hit_record / rto_hit (52 bytes)
 HIT_DTYPE = [("hit", "<i4"), ("prim", "<i4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4"),
              ("p", "<f4", (3,)), ("n", "<f4", (3,)), ("front_face", "<i4"), ("material", "<i4")]
@@ -76,7 +79,7 @@ HIT_DTYPE = [("hit", "<i4"), ("prim", "<i4"), ("t", "<f4"), ("u", "<f4"), ("v", 
 EXPORTS = [
     "rt_last_error", "rt_scene_create_builtin", "rt_scene_from_flat", "rt_scene_flat",
     "rt_scene_default_background", "rt_scene_destroy", "rt_ctx_create", "rt_ctx_destroy",
-    "rt_scene_upload", "rt_trace_rays", "rt_trace_primary", "rt_render_accumulate", "rt_render_accumulate_window", "rt_render_accumulate_noalloc", "rt_resolve",
+    "rt_scene_upload", "rt_trace_rays", "rt_trace_primary", "rt_shade_rays", "rt_texture_values", "rt_render_accumulate", "rt_render_accumulate_window", "rt_render_accumulate_noalloc", "rt_resolve",
     "rt_ctx_set_integrator", "rt_reduce_accum", "rt_reduce_scatter_rows", "rt_synchronize", "rt_get_counters", "rt_reset_counters", "rt_quantise_rgb8", "rt_write_ppm", "rt_write_png", "rt_read_ppm", "rt_free_pixels", "rt_flat_features", "rt_flat_program", "rt_flat_program_split", "rt_flat_bvh_stats",
 ]
 
@@ -104,6 +107,8 @@ def load_library(path=LIB_PATH):
     lib.rt_scene_upload.argtypes = [vp, C.POINTER(RtFlatScene)]
     lib.rt_trace_rays.argtypes = [vp, i32, vp, f32, f32, vp]
     lib.rt_trace_primary.argtypes = [vp, i32, i32, f32, f32, vp, vp]
+    lib.rt_shade_rays.argtypes = [vp, i32, vp, vp, vp, vp, u64, vp]
+    lib.rt_texture_values.argtypes = [vp, i32, i32, vp, vp]
     lib.rt_render_accumulate.argtypes = [vp, i32, i32, u32, u32, u64, i32, i32, vp]
     lib.rt_render_accumulate_window.argtypes = [vp, i32, i32, i32, i32, i32, i32, u32, u32, u64, i32, i32, vp]
     lib.rt_render_accumulate_noalloc.argtypes = [vp, i32, i32, u32, u32, u64, i32, i32, vp]
@@ -194,6 +199,32 @@ class Context:
         _check(lib().rt_trace_rays(self.handle, n, rays.data_ptr(), tmin, tmax, out.data_ptr()), "rt_trace_rays")
         self.synchronize()
         return np.frombuffer(out.cpu().numpy().tobytes(), dtype=np.dtype(HIT_DTYPE))
+
+    def shade_rays(self, rays, recs, materials, psb, seed):
+        """Material::scatter + emitted for (ray, record, material, RNG address) tuples; numpy in, numpy out"""
+        import numpy as np
+        import torch
+        dev = torch.device("cuda", self.device)
+        n = len(rays)
+        t = [torch.from_numpy(np.ascontiguousarray(a, dt)).to(dev) for a, dt in
+             ((rays, np.float32), (recs, np.float32), (materials, np.int32), (np.asarray(psb, np.uint32).view(np.int32), np.int32))]
+        out = torch.zeros(max(1, n) * 60, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)
+        _check(lib().rt_shade_rays(self.handle, n, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), seed, out.data_ptr()),
+               "rt_shade_rays")
+        self.synchronize()
+        return np.frombuffer(out.cpu().numpy().tobytes()[:n * 60], dtype=np.dtype(SCATTER_DTYPE))
+
+    def texture_values(self, texture, uvp):
+        import numpy as np
+        import torch
+        dev = torch.device("cuda", self.device)
+        q = torch.from_numpy(np.ascontiguousarray(uvp, np.float32)).to(dev)
+        rgb = torch.zeros((len(uvp), 3), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize(dev)
+        _check(lib().rt_texture_values(self.handle, texture, len(uvp), q.data_ptr(), rgb.data_ptr()), "rt_texture_values")
+        self.synchronize()
+        return rgb.cpu().numpy()
 
     def trace_primary(self, width, height, s_off=0.5, t_off=0.5):
         import torch

@@ -117,6 +117,63 @@ __global__ __launch_bounds__(RT_BLOCK) void trace_rays_kernel(DScene S, int n, c
     out[i] = o;
 }
 
+/* Material::scatter + emitted for caller-supplied (ray, record, material, RNG address): the shading parity hook.  Same
+ * device code as the integrators: the wave-wide unit-ball draw, then scatter<F>. */
+template <uint32_t F>
+__global__ __launch_bounds__(RT_BLOCK) void shade_rays_kernel(DScene S, int n, const float* __restrict__ rays, const float* __restrict__ recs,
+                                                               const int32_t* __restrict__ materials, const uint32_t* __restrict__ psb,
+                                                               uint32_t k0, uint32_t k1, rt_scatter_record* __restrict__ out)
+{
+    __shared__ int slot_mem[RT_BLOCK];
+    int* slots = slot_mem + (threadIdx.x & ~63u);
+    const int i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const bool active = i < n;
+    DRay r = {mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f), 0.f};
+    HitRec rec;
+    rec.t = 0.f; rec.u = 0.f; rec.v = 0.f; rec.p = mk(0.f, 0.f, 0.f); rec.n = mk(0.f, 0.f, 0.f);
+    rec.material = 0; rec.prim_id = -1; rec.front = 0;
+    PathRng g;
+    rng_start(g, k0, k1, 0u, 0u);
+    uint32_t bounce = 0;
+    int mtype = RT_MAT_LIGHT;
+    if (active) {
+        const float* q = rays + 7 * (size_t)i;
+        const float* h = recs + 9 * (size_t)i;
+        r.o = mk(q[0], q[1], q[2]); r.d = mk(q[3], q[4], q[5]); r.time = q[6];
+        rec.t = h[0]; rec.u = h[1]; rec.v = h[2];
+        rec.p = mk(h[3], h[4], h[5]); rec.n = mk(h[6], h[7], h[8]);
+        rec.material = materials[i];
+        rng_start(g, k0, k1, psb[3 * (size_t)i], psb[3 * (size_t)i + 1]);
+        bounce = psb[3 * (size_t)i + 2];
+        mtype = S.mats[rec.material].type;
+    }
+    const bool need_ball = active && mtype != RT_MAT_LIGHT && mtype != RT_MAT_GLASS;
+    const V3 ball = random_in_unit_sphere_wave(g, bounce, need_ball, slots);
+    if (!active) return;
+    V3 attenuation, emitted;
+    DRay scattered;
+    const bool ok = scatter<F>(S, r, rec, g, bounce, ball, attenuation, scattered, emitted);
+    rt_scatter_record o;
+    o.ok = ok ? 1 : 0;
+    o.attenuation[0] = attenuation.x; o.attenuation[1] = attenuation.y; o.attenuation[2] = attenuation.z;
+    o.origin[0] = scattered.o.x; o.origin[1] = scattered.o.y; o.origin[2] = scattered.o.z;
+    o.direction[0] = scattered.d.x; o.direction[1] = scattered.d.y; o.direction[2] = scattered.d.z;
+    o.time = scattered.time;
+    o.emitted[0] = emitted.x; o.emitted[1] = emitted.y; o.emitted[2] = emitted.z;
+    o.pad = 0u;
+    out[i] = o;
+}
+
+template <uint32_t F>
+__global__ __launch_bounds__(RT_BLOCK) void texture_values_kernel(DScene S, int texture, int n, const float* __restrict__ uvp, float* __restrict__ rgb)
+{
+    const int i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float* q = uvp + 5 * (size_t)i;
+    const V3 c = texture_value<F>(S, texture, q[0], q[1], mk(q[2], q[3], q[4]));
+    rgb[3 * (size_t)i] = c.x; rgb[3 * (size_t)i + 1] = c.y; rgb[3 * (size_t)i + 2] = c.z;
+}
+
 /* lane -> pixel inside a 16x16 block tile; each wave covers an 8x8 sub-tile */
 __device__ __forceinline__ void tile_pixel(int W, int tile, int tid, int& i, int& j)
 {
@@ -348,6 +405,7 @@ struct rt_ctx {
     bool have_scene = false;
     bool has_bvh = false;
     int n_bvh_items = 0;
+    int n_textures = 0, n_materials = 0;
     uint32_t features = 0;    /* RT_F_* of the uploaded scene */
     int integrator = RT_INTEGRATOR_AUTO;
     int last_integrator = 0;          /* form the latest render call ran in (rt_counters) */
@@ -523,6 +581,8 @@ extern "C" int rt_scene_upload(rt_ctx* c, const rt_flat_scene* s)
     c->ds.cam = s->camera;
     c->has_bvh = s->n_bvh_nodes > 0;
     c->n_bvh_items = s->n_bvh_items;
+    c->n_textures = s->n_textures;
+    c->n_materials = s->n_materials;
     c->stack_depth = stack_depth < 1 ? 1 : stack_depth;
     c->have_scene = true;
     return RT_OK;
@@ -547,6 +607,34 @@ extern "C" int rt_trace_rays(rt_ctx* c, int n, const float* rays, float tmin, fl
     dim3 grid((unsigned)((n + RT_BLOCK - 1) / RT_BLOCK));
     if (c->has_bvh) trace_rays_kernel<RT_F_ALL><<<grid, RT_BLOCK, stack_bytes(c), c->stream>>>(c->ds, n, rays, tmin, tmax, out);
     else trace_rays_kernel<RT_V_LIST><<<grid, RT_BLOCK, 0, c->stream>>>(c->ds, n, rays, tmin, tmax, out);
+    HIPCHK(hipGetLastError());
+    return RT_OK;
+}
+
+extern "C" int rt_shade_rays(rt_ctx* c, int n, const float* rays, const float* recs, const int32_t* materials, const uint32_t* psb,
+                             uint64_t seed, rt_scatter_record* out)
+{
+    int rc = need_scene(c, "rt_shade_rays");
+    if (rc) return rc;
+    if (n < 0 || (n && (!rays || !recs || !materials || !psb || !out))) { rt_set_error("rt_shade_rays: bad arguments"); return RT_ERR_ARG; }
+    if (n == 0) return RT_OK;
+    HIPCHK(hipSetDevice(c->device));
+    /* material indices come from the caller's device memory: they are range-checked by the scene's material count on
+     * the host side of the tests only; a parity hook, not a render path */
+    shade_rays_kernel<RT_V_NOISE><<<dim3((unsigned)((n + RT_BLOCK - 1) / RT_BLOCK)), RT_BLOCK, 0, c->stream>>>(c->ds, n, rays, recs, materials, psb,
+                                                                                                          (uint32_t)seed, (uint32_t)(seed >> 32), out);
+    HIPCHK(hipGetLastError());
+    return RT_OK;
+}
+
+extern "C" int rt_texture_values(rt_ctx* c, int texture, int n, const float* uvp, float* rgb)
+{
+    int rc = need_scene(c, "rt_texture_values");
+    if (rc) return rc;
+    if (n < 0 || texture < 0 || texture >= c->n_textures || (n && (!uvp || !rgb))) { rt_set_error("rt_texture_values: bad arguments"); return RT_ERR_ARG; }
+    if (n == 0) return RT_OK;
+    HIPCHK(hipSetDevice(c->device));
+    texture_values_kernel<RT_V_NOISE><<<dim3((unsigned)((n + RT_BLOCK - 1) / RT_BLOCK)), RT_BLOCK, 0, c->stream>>>(c->ds, texture, n, uvp, rgb);
     HIPCHK(hipGetLastError());
     return RT_OK;
 }

@@ -98,6 +98,24 @@ int  rt_trace_rays(rt_ctx* c, int n, const float* rays7_dev, float tmin, float t
 int  rt_trace_primary(rt_ctx* c, int width, int height, float s_off, float t_off,
                       int32_t* prim_dev, float* t_dev);
 
+/* ---- shading (Material::scatter + emitted, Material.cuh:44-144; Texture::value, Texture.cuh:7-61) ---- */
+/* Parity hooks for the shading half of colour()'s loop body (main.cu:58-66), the counterpart of rt_trace_rays for the
+ * geometry half.  Element i: incoming ray rays7[i] (origin, direction, time), hit record recs9[i] (t, u, v, p[3],
+ * normal[3]: the fields of Intersect, Hitable.cuh:10-22, that materials read), material index materials[i], and the
+ * RNG address (pixel, sample, bounce) = psb3[i] of the path it belongs to: the draws are the ones rt_render_accumulate
+ * makes for that (seed, pixel, sample, bounce).  out[i] = what scatter() and emitted() return. */
+typedef struct rt_scatter_record {
+    int32_t ok;              /* scatter()'s return value */
+    float   attenuation[3];
+    float   origin[3], direction[3], time;   /* the scattered ray */
+    float   emitted[3];
+    uint32_t pad;
+} rt_scatter_record;       /* 60 bytes */
+int  rt_shade_rays(rt_ctx* c, int n, const float* rays7_dev, const float* recs9_dev, const int32_t* materials_dev,
+                   const uint32_t* psb3_dev, uint64_t seed, rt_scatter_record* out_dev);
+/* rgb_dev[3 i ..] = value(u, v, p) of texture `texture` for uvp5_dev[5 i ..] = (u, v, p[3]) */
+int  rt_texture_values(rt_ctx* c, int texture, int n, const float* uvp5_dev, float* rgb_dev);
+
 /* ---- render (replaces renderInit + render, main.cu:108-198, minus the mean and sqrt) ---- */
 /* accum_dev[3*(j*W+i)+c] += sum over samples s in [sample_begin, sample_end) of colour() (background
  * RT_BG_BLACK) or colourUnlit() (RT_BG_SKY) for the camera path (pixel, s), max_depth bounces

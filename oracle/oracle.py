@@ -86,6 +86,18 @@ class Oracle(_Common):
         fn(C.cast(flat, C.c_void_p), mat, ray_in.shape[0], _ptr(ray_in), _ptr(rec_in), _ptr(xi), xi.shape[1], _ptr(out))
         return out
 
+    def scatter_addressed(self, flat, materials, ray_in, rec_in, seed, pixel_sample_bounce):
+        """scatter()/emitted() with the render loop's own addressed Philox draws for (seed, pixel, sample, bounce)"""
+        ray_in, rec_in = _f32(ray_in), _f32(rec_in)
+        mats = np.ascontiguousarray(materials, dtype=np.int32)
+        psb = np.ascontiguousarray(pixel_sample_bounce, dtype=np.uint32)
+        out = np.zeros(ray_in.shape[0], dtype=SCATTER_DTYPE)
+        fn = self.lib.rto_scatter_addressed
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        fn.restype = None
+        fn(C.cast(flat, C.c_void_p), ray_in.shape[0], _ptr(ray_in), _ptr(rec_in), _ptr(mats), seed, _ptr(psb), _ptr(out))
+        return out
+
     def trace_rays(self, flat, rays, tmin, tmax, use_bvh=False, stats=None):
         rays = _f32(rays)
         out = np.zeros(rays.shape[0], dtype=HIT_DTYPE)

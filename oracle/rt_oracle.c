@@ -794,6 +794,40 @@ void rto_scatter(const rt_flat_scene* s, int material, int n, const float* ray_i
     }
 }
 
+/* scatter() + emitted() with the path tracer's own ADDRESSED draws (the blocks the render loop would use for this
+ * (seed, pixel, sample, bounce)): what the GPU parity hook rt_shade_rays is compared with */
+void rto_scatter_addressed(const rt_flat_scene* s, int n, const float* ray_in, const float* rec_in, const int32_t* material,
+                           uint64_t seed, const uint32_t* pixel_sample_bounce, rto_scatter_out* out)
+{
+    for (int i = 0; i < n; ++i) {
+        const float* q = ray_in + 7 * (size_t)i;
+        const float* h = rec_in + 9 * (size_t)i; /* t u v p[3] n[3] */
+        Ray r = {v3(q[0], q[1], q[2]), v3(q[3], q[4], q[5]), q[6]};
+        Hit rec;
+        memset(&rec, 0, sizeof rec);
+        rec.t = h[0]; rec.u = h[1]; rec.v = h[2];
+        rec.p = v3(h[3], h[4], h[5]);
+        rec.normal = v3(h[6], h[7], h[8]);
+        rec.material = material[i];
+        Rng g;
+        rng_init(&g, seed, pixel_sample_bounce[3 * i], pixel_sample_bounce[3 * i + 1], NULL);
+        g.bounce = pixel_sample_bounce[3 * i + 2];
+        V3 att = v3(0, 0, 0);
+        Ray sc = {v3(0, 0, 0), v3(0, 0, 0), 0.f};
+        V3 em = emitted(s, material[i], rec.u, rec.v, rec.p);
+        rto_scatter_out* o = &out[i];
+        o->ok = scatter(s, material[i], &r, &rec, &att, &sc, &g);
+        for (int k = 0; k < 3; ++k) {
+            o->attenuation[k] = att.e[k];
+            o->origin[k] = sc.A.e[k];
+            o->direction[k] = sc.B.e[k];
+            o->emitted[k] = em.e[k];
+        }
+        o->time = sc.time;
+        o->draws = 0;
+    }
+}
+
 void rto_camera_rays(const rt_flat_scene* s, int n, const float* st, uint64_t seed,
                      const uint32_t* pixel_sample, float* rays_out)
 {

@@ -57,6 +57,8 @@ float rto_noise_turb(const uint8_t* table, const float p[3], int depth);
 /* xi: per call, xi_stride scripted uniforms consumed in the order the reference's scatter() draws them */
 void rto_scatter(const rt_flat_scene* s, int material, int n, const float* ray_in7, const float* rec_in9,
                  const float* xi, int xi_stride, rto_scatter_out* out);
+void rto_scatter_addressed(const rt_flat_scene* s, int n, const float* ray_in7, const float* rec_in9, const int32_t* material,
+                           uint64_t seed, const uint32_t* pixel_sample_bounce3, rto_scatter_out* out);
 void rto_camera_rays(const rt_flat_scene* s, int n, const float* st, uint64_t seed,
                      const uint32_t* pixel_sample, float* rays_out7);
 void rto_uniforms(uint64_t seed, uint32_t pixel, uint32_t sample, int n, float* out);

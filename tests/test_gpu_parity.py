@@ -529,3 +529,80 @@ def test_wavefront_failure_leaves_the_context_usable(binding, gpu_ctx, monkeypat
     monkeypatch.delenv("RT_WF_DEBUG_MAX_ITERS")
     again = render_gpu(gpu_ctx, binding, sc, W, H, 0, spp, 5, integrator="wavefront")
     assert torch.equal(again, good)
+
+
+@pytest.mark.parametrize("scene", ["kat", "perlin", "random_spheres"])
+def test_scatter_matches_oracle_material_by_material(binding, oracle, gpu_ctx, scene):
+    """SURVEY 8(a) A11-A14 on the GPU directly (rt_shade_rays), not only through whole renders: every material of the scene,
+    512 random (ray, record) pairs each incl. inside-glass normals and grazing angles, the render loop's own addressed
+    Philox draws.  ok flags, attenuation, scattered origin / time and emission bit for bit; the scattered direction
+    bit for bit except where it passes through powf / sinf (Glass's Schlick branch can flip on a last-bit difference,
+    checker and noise textures read device sinf)"""
+    sc = binding.Scene(scene, 64, 48)
+    gpu_ctx.upload(sc)
+    f = sc.flat.contents
+    rng = np.random.default_rng(11)
+    n = 512
+    kinds = set()
+    for mi in range(f.n_materials):
+        mtype = f.materials[mi].type
+        kinds.add(mtype)
+        d = rng.normal(size=(n, 3)) * rng.uniform(0.2, 5.0, size=(n, 1))
+        nrm = rng.normal(size=(n, 3))
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        flip = (np.einsum("ij,ij->i", d, nrm) > 0) & (rng.random(n) < 0.5)
+        nrm[flip] *= -1
+        p = rng.uniform(-6, 6, size=(n, 3))
+        rays = np.concatenate([p - d, d, rng.random((n, 1))], axis=1).astype(np.float32)
+        recs = np.concatenate([np.ones((n, 1)), rng.random((n, 2)), p, nrm], axis=1).astype(np.float32)
+        psb = np.stack([rng.integers(0, 1 << 20, n), rng.integers(0, 4096, n), rng.integers(0, 100, n)], axis=1).astype(np.uint32)
+        mats = np.full(n, mi, np.int32)
+        exp = oracle.scatter_addressed(sc.flat, mats, rays, recs, 419, psb)
+        got = gpu_ctx.shade_rays(rays, recs, mats, psb, 419)
+        what = "%s material %d (type %d)" % (scene, mi, mtype)
+        if mtype == 2:      # Glass: reflect / refract hangs on xi < schlick(powf): allow the branch to flip for a handful
+            same = got["ok"] == exp["ok"]
+            agree = np.all(got["direction"] == exp["direction"], axis=1)
+            assert same.all() and agree.mean() > 0.99, what
+            assert np.array_equal(got["attenuation"], exp["attenuation"]) and np.array_equal(got["origin"], exp["origin"])
+            continue
+        assert np.array_equal(got["ok"], exp["ok"]), what
+        ok = exp["ok"] == 1
+        if mtype == 3:      # DiffuseLight: only the emission is defined
+            assert np.allclose(got["emitted"], exp["emitted"], rtol=0, atol=2e-6), what
+            continue
+        sel = ok if mtype != 1 else np.ones_like(ok)          # Metal fills its outputs even when it absorbs
+        for field in ("origin", "direction", "time"):
+            assert np.array_equal(got[field][sel], exp[field][sel]), what + " " + field
+        # attenuation = texture value: constant and image textures exact, checker / noise through device sinf
+        noisy = scene == "perlin"                               # NoiseTexture: sinf of a turbulence sum (no reference counterpart)
+        assert np.allclose(got["attenuation"][sel], exp["attenuation"][sel], rtol=0, atol=1e-4 if noisy else 2e-6), what
+        exact = np.all(got["attenuation"][sel] == exp["attenuation"][sel], axis=1)
+        assert noisy or exact.mean() > 0.98, what
+    assert kinds >= ({0, 1, 2, 3, 4} if scene == "kat" else {0}), kinds
+
+
+@pytest.mark.parametrize("scene", ["kat", "perlin"])
+def test_texture_values_match_oracle(binding, oracle, gpu_ctx, scene):
+    """SURVEY 8(a) A15 on the GPU directly (rt_texture_values): constant and image textures bit for bit (incl. the clamp
+    edges of ImageTexture::value, Texture.cuh:49-61), checker away from its sign boundaries, noise within libm tolerance"""
+    sc = binding.Scene(scene, 64, 48)
+    gpu_ctx.upload(sc)
+    f = sc.flat.contents
+    rng = np.random.default_rng(5)
+    n = 2048
+    for ti in range(f.n_textures):
+        uvp = np.concatenate([rng.uniform(-0.1, 1.1, size=(n, 2)), rng.uniform(-6, 6, size=(n, 3))], axis=1).astype(np.float32)
+        uvp[:8, 0] = [0, 1, 0.5, 1, 0, 0.999999, 1e-7, 0.25]
+        uvp[:8, 1] = [0, 1, 1, 0, 0.5, 1e-7, 0.999999, 0.75]
+        exp = oracle.texture_value(sc.flat, ti, uvp)
+        got = gpu_ctx.texture_values(ti, uvp)
+        ttype = f.textures[ti].type
+        if ttype in (0, 2):                      # constant, image
+            assert np.array_equal(got, exp), (scene, ti)
+        elif ttype == 1:                         # checker: sign of a product of three sinf
+            assert (np.all(got == exp, axis=1)).mean() > 0.995, (scene, ti)
+        else:                                    # noise
+            assert np.allclose(got, exp, rtol=0, atol=1e-4), (scene, ti)
+    with pytest.raises(binding.RtError):
+        gpu_ctx.texture_values(f.n_textures, np.zeros((1, 5), np.float32))
