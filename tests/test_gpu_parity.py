@@ -600,8 +600,9 @@ def test_texture_values_match_oracle(binding, oracle, gpu_ctx, scene):
         ttype = f.textures[ti].type
         if ttype in (0, 2):                      # constant, image
             assert np.array_equal(got, exp), (scene, ti)
-        elif ttype == 1:                         # checker: sign of a product of three sinf
-            assert (np.all(got == exp, axis=1)).mean() > 0.995, (scene, ti)
+        elif ttype == 1:                         # checker: sign of a product of three sinf picks the child; perlin's children are noise
+            same = np.all(got == exp, axis=1) if scene == "kat" else np.all(np.abs(got - exp) <= 1e-4, axis=1)
+            assert same.mean() > 0.995, (scene, ti)
         else:                                    # noise
             assert np.allclose(got, exp, rtol=0, atol=1e-4), (scene, ti)
     with pytest.raises(binding.RtError):
