@@ -495,10 +495,12 @@ static bool png_chunk(FILE* f, const char type[4], const std::vector<uint8_t>& b
     png_be32(head, (uint32_t)body.size());
     head.insert(head.end(), type, type + 4);
     uint32_t crc = png_crc(head.data() + 4, 4, 0xffffffffu);
-    crc = png_crc(body.data(), body.size(), crc) ^ 0xffffffffu;
+    if (!body.empty()) crc = png_crc(body.data(), body.size(), crc);
+    crc ^= 0xffffffffu;
     std::vector<uint8_t> tail;
     png_be32(tail, crc);
-    return std::fwrite(head.data(), 1, 8, f) == 8 && std::fwrite(body.data(), 1, body.size(), f) == body.size() &&
+    /* IEND has an empty body: fwrite must not be handed a null pointer, not even for zero bytes */
+    return std::fwrite(head.data(), 1, 8, f) == 8 && (body.empty() || std::fwrite(body.data(), 1, body.size(), f) == body.size()) &&
            std::fwrite(tail.data(), 1, 4, f) == 4;
 }
 
