@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--param", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--integrator", default="auto", choices=["auto", "megakernel", "wavefront"])
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary workload line of the default run")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other configs' lines of the default run (the last one takes a minute)")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for RCCL; must be set before the first HIP call
@@ -292,8 +292,15 @@ def main():
         if world == 1 and args.workload == "cornell" and not args.no_extras:
             # the north_star target scene beside the headline one: BASELINE.json configs[3] as it stands
             # (1M triangles, 1920x1080, 256 spp in one call: ~1.5 s per step)
-            extra = run("tri_mesh", 0, 0, 0, -1, 1, 1, False)
-            out["also"] = [{k: extra[k] for k in ("value", "unit", "ms_per_step", "config", "samples_per_s", "rays_per_sample", "roofline")}]
+            keys = ("value", "unit", "steps", "warmup", "ms_per_step", "config", "samples_per_s", "rays_per_sample", "roofline")
+            out["also"] = []
+            # ... and the other two GPU configs at their full size, one step each, so that every BASELINE config has a
+            # line timed by whoever runs this file: configs[2] Cornell smoke (0.5 s) and configs[4] the final scene with
+            # 100 x 100 boxes at 3840x2160 x 4096 spp (about a minute on one GPU; no warm-up step)
+            for wl, steps, warm in (("tri_mesh", 1, 1), ("cornell_smoke", 1, 1), ("final", 1, 0)):
+                extra = run(wl, 0, 0, 0, -1, steps, warm, False)
+                out["also"].append({k: extra[k] for k in keys})
+                print("bench.py: %s done, %.0f Mrays/s" % (wl, extra["value"]), file=sys.stderr, flush=True)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -746,8 +746,41 @@ static int wf_reserve(rt_ctx* c, size_t n_slots)
 }
 
 template <uint32_t V>
+static int wf_run_part(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t s1, uint32_t k0, uint32_t k1, int max_depth,
+                       int background, float* accum);
+
+/* A slot runs its samples one after the other, and the queue is written afresh in every iteration in the order in which
+ * the logic kernel's blocks happen to finish: over hundreds of iterations the queue drifts away from slot order and
+ * the state accesses lose their coalescing.  Measured on the final scene at 3840x2160 (16 streams per pixel), 512 spp
+ * rendered as one part / parts of 256 / 128 / 64 samples: 3.48 / 3.56 / 3.62 / 3.67 Grays/s; all 4096 spp as one part: 3.14.
+ * Each part starts from a queue in slot order, but also ends with a drain, so parts of one sample per stream lose
+ * again (1M triangles, 64 streams: 256 spp as one part 2.72, as four parts 2.62).  A call is therefore cut into parts
+ * of FOUR samples per stream.  A call with a single stream per pixel is left whole: it then sums a pixel's samples in
+ * the megakernel's order and has its bits (tests/test_gpu_parity.py). */
+#ifndef WF_PART_SAMPLES
+#define WF_PART_SAMPLES 4
+#endif
+template <uint32_t V>
 static int wf_run(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t s1, uint32_t k0, uint32_t k1, int max_depth,
                   int background, float* accum)
+{
+    const size_t n_pixels = (size_t)win.z * (size_t)win.w;
+    size_t streams = (c->wf_slots_target + n_pixels - 1) / n_pixels;       /* what wf_run_part will settle on, or a little more */
+    if (streams > s1 - s0) streams = s1 - s0;
+    unsigned long long part = (unsigned long long)WF_PART_SAMPLES * (streams < 1 ? 1 : streams);
+    if (const char* e = std::getenv("RT_WF_PART")) { const long long v = std::atoll(e); if (v > 0) part = (unsigned long long)v; else part = ~0ull; }
+    if (streams <= 1 || (unsigned long long)(s1 - s0) <= part + part / 2) return wf_run_part<V>(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum);
+    for (unsigned long long a = s0; a < s1; a += part) {
+        const uint32_t b = a + part < s1 ? (uint32_t)(a + part) : s1;
+        int rc = wf_run_part<V>(c, w, h, win, (uint32_t)a, b, k0, k1, max_depth, background, accum);
+        if (rc) return rc;
+    }
+    return RT_OK;
+}
+
+template <uint32_t V>
+static int wf_run_part(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t s1, uint32_t k0, uint32_t k1, int max_depth,
+                       int background, float* accum)
 {
     const uint32_t n_pixels = (uint32_t)win.z * (uint32_t)win.w;
     /* about RT_WF_SLOTS paths in flight (each persistent lane should see many rays per launch, so that the

@@ -60,7 +60,11 @@ def derived(wl, k):
     """VALU busy share of the SIMDs (SQ_ACTIVE_INST_VALU counts quad-cycles; GRBM_GUI_ACTIVE is summed over the
     8 XCDs), lane efficiency (active lanes per VALU instruction / 64) and, where counted, the L2 hit rate"""
     simd_cycles = g(wl, k, "GRBM_GUI_ACTIVE") / 8.0 * 1024.0
-    out = {"valu_busy": 4.0 * g(wl, k, "SQ_ACTIVE_INST_VALU") / simd_cycles if simd_cycles else None,
+    busy = 4.0 * g(wl, k, "SQ_ACTIVE_INST_VALU") / simd_cycles if simd_cycles else None
+    out = {"valu_busy": busy,
+           # the formula is not calibrated beyond 1 (packed and transcendental instructions hold a pipe for other than 4
+           # cycles): at or above 1 the only thing it says is "an instruction issues in every cycle"
+           "valu_issue": None if busy is None else ("saturated" if busy >= 0.98 else "%.0f %% busy" % (100.0 * busy)),
            "lane_efficiency": g(wl, k, "SQ_THREAD_CYCLES_VALU") / (64.0 * g(wl, k, "SQ_ACTIVE_INST_VALU")) if g(wl, k, "SQ_ACTIVE_INST_VALU") else None,
            "wait_share_of_wave_cycles": g(wl, k, "SQ_WAIT_ANY") / g(wl, k, "SQ_WAVE_CYCLES") if g(wl, k, "SQ_WAVE_CYCLES") else None}
     if g(wl, k, "TCC_REQ_sum"):

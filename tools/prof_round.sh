@@ -4,7 +4,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-r02a}
 mkdir -p $O
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_default -- python3 bench.py --no-cpu-baseline > $O/trace_default.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_default -- python3 bench.py --no-cpu-baseline --no-extras > $O/trace_default.log 2>&1
 C="python3 bench.py --no-cpu-baseline --no-extras --steps 1 --warmup 0"
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/cornell_fetch -- $C > $O/cornell_fetch.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/cornell_write -- $C > $O/cornell_write.log 2>&1
