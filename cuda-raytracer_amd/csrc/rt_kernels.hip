@@ -49,6 +49,7 @@
 #endif
 #define RT_N_COUNTERS 16        /* rays, samples, then diagnostic slots */
 #define WF_MAX_POOLS 4
+#define WF_POOL_COUNT_WORDS (9 * 32)   /* per pool: one 128-B line of queue lengths + legacy head, then a line per band head */
 #ifndef WF_POOLS_DEFAULT
 #define WF_POOLS_DEFAULT 3
 #endif
@@ -664,8 +665,6 @@ static int note_render(rt_ctx* c, hipEvent_t e0, hipEvent_t e1)
 }
 
 /* ------------------------------------------------------------ wavefront host -- */
-__global__ void wf_reset_kernel(uint32_t* count, int which) { count[which] = 0u; count[2] = 0u; }
-
 /* Streams for the pools.  A process has few hardware queues (GPU_MAX_HW_QUEUES, 4 here) and the runtime spreads its
  * streams over them; two streams on one queue run their kernels one after the other, and pools that do not overlap
  * are worse than one pool.  Which streams share a queue cannot be asked, so it is measured once per context: a kernel
@@ -722,7 +721,8 @@ static int wf_reserve(rt_ctx* c, size_t n_slots)
     if (n_slots > c->wf_slots_cap) {
         HIPCHK(hipStreamSynchronize(c->stream));
         if (c->wf_mem) { (void)hipFree(c->wf_mem); c->wf_mem = nullptr; c->wf_slots_cap = 0; }
-        const size_t bytes = n_slots * (5 * sizeof(float4) + 2 * sizeof(uint32_t)) + 256;
+        const size_t bytes = n_slots * (5 * sizeof(float4) + 2 * sizeof(uint32_t)) + WF_MAX_POOLS * WF_POOL_COUNT_WORDS * sizeof(uint32_t) + 128
+                             + (n_slots / WF_SPAN + 2 * WF_MAX_POOLS + 1) * sizeof(uint32_t);
         if (hipMalloc(&c->wf_mem, bytes) != hipSuccess) {
             (void)hipGetLastError();
             c->wf_mem = nullptr;
@@ -741,7 +741,8 @@ static int wf_reserve(rt_ctx* c, size_t n_slots)
     c->wf.hit   = (float4*)p; p += cap * sizeof(float4);
     c->wf.queue[0] = (uint32_t*)p; p += cap * sizeof(uint32_t);
     c->wf.queue[1] = (uint32_t*)p; p += cap * sizeof(uint32_t);
-    c->wf.count = (uint32_t*)p;
+    c->wf.count = (uint32_t*)(((uintptr_t)p + 127u) & ~(uintptr_t)127u);      /* the counters' lines are 128-B aligned */
+    c->wf.scan = c->wf.count + WF_MAX_POOLS * WF_POOL_COUNT_WORDS;             /* cap / WF_SPAN + 2 * WF_MAX_POOLS + 1 words */
     return RT_OK;
 }
 
@@ -806,6 +807,8 @@ static int wf_run_part(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t 
      * lanes.  Measured at 1080p (tools/refill_sweep.py), Grays/s at 16 / 24 / 32 / 40 / 48 / 56 idle lanes: final scene
      * (11 plain records) 2.78 / 2.93 / 3.01 / 3.04 / 3.01 / 2.90; 1M triangles (1 record) 2.08 / 2.10 / 2.12 / 2.12 / 2.12 / 2.09 */
     W.refill_min = 40;
+    W.affine = 0;
+    if (const char* e = std::getenv("RT_WF_AFFINE")) W.affine = std::atoi(e) ? 1 : 0;
     /* RT_WF_REFILL in the environment overrides it (how those figures were measured) */
     if (const char* e = std::getenv("RT_WF_REFILL")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) W.refill_min = v; }
     if (c->stack4 > WF_LDS_STACK + WF_OVF_STACK) { rt_set_error("wavefront integrator: BVH deeper than its traversal stack"); return RT_ERR_UNSUPPORTED; }
@@ -831,7 +834,7 @@ static int wf_run_part(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t 
     struct Pool { WfState W; hipStream_t st; uint32_t known; int cur; bool pending; unsigned long long iters, max_iters; uint32_t* host; };
     Pool pools[WF_MAX_POOLS];
     W.stream0 = 0;
-    HIPCHK(hipMemsetAsync(W.count, 0, 4 * WF_MAX_POOLS * sizeof(uint32_t), c->stream));
+    HIPCHK(hipMemsetAsync(W.count, 0, WF_MAX_POOLS * WF_POOL_COUNT_WORDS * sizeof(uint32_t), c->stream));
     for (int p = 0; p < n_pools; ++p) {
         Pool& P = pools[p];
         const uint32_t k_first = (uint32_t)((unsigned long long)streams * p / n_pools);
@@ -840,7 +843,8 @@ static int wf_run_part(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t 
         std::memcpy((void*)&P.W, (const void*)&W, sizeof(WfState));
         P.W.ray_o += off; P.W.ray_d += off; P.W.att += off; P.W.sum += off; P.W.hit += off;
         P.W.queue[0] += off; P.W.queue[1] += off;
-        P.W.count = W.count + 4 * p;
+        P.W.count = W.count + WF_POOL_COUNT_WORDS * p;
+        P.W.scan = W.scan + off / WF_SPAN + 2 * (size_t)p;
         P.W.n_slots = k_count * n_pixels;
         P.W.stream0 = k_first;
         P.st = n_pools == 1 ? c->stream : c->wf_streams[p];
@@ -886,15 +890,16 @@ static int wf_run_part(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t 
                 if (P.iters > P.max_iters) { rt_set_error("wavefront integrator: the path queue did not drain"); return RT_ERR_HIP; }
                 P.iters += (unsigned)batch;
                 for (int b = 0; b < batch; ++b) {
-                    wf_reset_kernel<<<1, 1, 0, P.st>>>(P.W.count, P.cur ^ 1);
                     const unsigned blocks = (P.known + RT_BLOCK - 1) / RT_BLOCK;
                     const unsigned iblocks = blocks < iblocks_max ? blocks : iblocks_max;
-                    const unsigned lblocks = (P.known + RT_BLOCK * WF_LOGIC_TILES - 1) / (RT_BLOCK * WF_LOGIC_TILES);
+                    const unsigned lblocks = (P.known + WF_SPAN - 1) / WF_SPAN;
                     wf_intersect_kernel<(V & ~RT_F_NOISE)><<<dim3(iblocks), RT_BLOCK, lds, P.st>>>(c->ds, P.W, P.cur, k0, k1, c->d_counters);   /* reads no texture */
                     if (background == RT_BG_BLACK)
                         wf_logic_kernel<V, RT_BG_BLACK><<<dim3(lblocks), RT_BLOCK, 0, P.st>>>(c->ds, P.W, P.cur, w, h, s1, k0, k1, max_depth);
                     else
                         wf_logic_kernel<V, RT_BG_SKY><<<dim3(lblocks), RT_BLOCK, 0, P.st>>>(c->ds, P.W, P.cur, w, h, s1, k0, k1, max_depth);
+                    wf_scan_kernel<<<1, 1024, 0, P.st>>>(P.W, P.cur);            /* survivors per span -> offsets; rewinds the fetch heads */
+                    wf_move_kernel<<<dim3(lblocks), RT_BLOCK, 0, P.st>>>(P.W, P.cur);
                     P.cur ^= 1;
                 }
                 HIPCHK(hipGetLastError());

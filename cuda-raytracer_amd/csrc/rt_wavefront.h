@@ -35,6 +35,7 @@ struct WfState {
     float4* __restrict__ hit;     /* t, object, group, aux (bits) */
     uint32_t* __restrict__ queue[2];
     uint32_t* __restrict__ count; /* [0],[1] = entries of queue[0],queue[1]; [2] = intersect fetch head */
+    uint32_t* __restrict__ scan;  /* n_slots / 1024 + 2 words: survivors per logic block, then their prefix sums */
     uint32_t n_slots, n_pixels, streams;    /* n_pixels = pixels of the rendered window; streams = sample streams per pixel of the whole call */
     uint32_t stream0;                       /* first stream of this pool (the slots of a call are run as one or two pools, rt_kernels.hip wf_run) */
     uint32_t win_x0, win_y0, win_w, frame_w;   /* the window inside the frame (rt_render_accumulate_window) */
@@ -44,6 +45,7 @@ struct WfState {
     const int* __restrict__ groups;
     int n_groups;
     int refill_min;    /* idle lanes that make a refill (and its run over the plain records) worth while */
+    int affine;        /* 1: a wave takes its chunks of the queue from the image band of its XCD first (below) */
 };
 
 /* slot -> pixel: stream k of window pixel p is slot k * n_pixels + p; returns the pixel's index in the FRAME,
@@ -70,6 +72,7 @@ enum { WF_NEED = 0, WF_BVH = 2 };
 #define WF_GENERAL_WAVES 4
 #endif
 constexpr int wf_intersect_waves(uint32_t F) { return (F & ~(RT_F_BVH | RT_F_TRI | RT_F_PLANAR)) == 0 ? 5 : WF_GENERAL_WAVES; }
+#define WF_HEAD_WORDS 32     /* a band's fetch head sits on a 128-B line of its own: count[32 (1 + band)] */
 #define WF_LDS_STACK 20      /* traversal-stack entries per lane kept in LDS; deeper ones go to scratch */
 #define WF_OVF_STACK 44      /* entries of the scratch overflow: 3 per level of a 4-wide tree, rarely reached */
 #ifndef WF_PRIM_BATCH
@@ -127,6 +130,12 @@ __global__ __launch_bounds__(RT_BLOCK, wf_intersect_waves(F)) void wf_intersect_
      * the whole grid, within [16, WF_CHUNK] */
     uint32_t chunk = n_queue / (gridDim.x * (RT_BLOCK / 64) * 2u);
     chunk = chunk < 16u ? 16u : (chunk > (uint32_t)WF_CHUNK ? (uint32_t)WF_CHUNK : chunk);
+    /* XCD-affine claims (see the refill): chunk ids, chunk ids per stream (at least 8, so that every band has one) */
+    const uint32_t af_chunks = (n_queue + chunk - 1u) / chunk;
+    const uint32_t af_streams = W.n_slots / (W.n_pixels ? W.n_pixels : 1u);
+    uint32_t af_cps = (af_chunks + (af_streams ? af_streams : 1u) - 1u) / (af_streams ? af_streams : 1u);
+    af_cps = af_cps < 8u ? 8u : af_cps;
+    int band = (int)(blockIdx.x & 7u), band_tried = 0;
 #ifdef RT_STAMPS
     unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* trips, busy lanes, node, prim, -, -, with prim, cycles */
     const unsigned long long dg_t0 = __builtin_amdgcn_s_memtime();
@@ -140,12 +149,48 @@ __global__ __launch_bounds__(RT_BLOCK, wf_intersect_waves(F)) void wf_intersect_
             /* The wave owns a chunk [chunk_next, chunk_end) of the queue and hands its entries to idle
              * lanes; one returning atomic on the shared head per WF_CHUNK rays (a single word sustains
              * ~90 M dequeues/s on this chip, far below the ray rate if every refill paid one). */
-            if (chunk_next >= chunk_end) {
+            if (chunk_next >= chunk_end && !W.affine) {
                 uint32_t b = 0;
                 if (lane == 0) b = atomicAdd(&W.count[2], chunk);
                 chunk_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
                 chunk_end = chunk_next + chunk < n_queue ? chunk_next + chunk : n_queue;
                 if (chunk_next >= n_queue) { drained = true; chunk_next = chunk_end = n_queue; }
+            }
+            /* XCD-affine claims.  The queue is (nearly) in slot order: stream after stream, inside a stream the pixels of
+             * the frame row by row.  Chunk c therefore lies in image band (c mod cps) * 8 / cps of its stream, cps =
+             * chunks per stream.  Band x has a head of its own (each on a cache line of its own) that enumerates the
+             * chunks of band x over all streams, and the waves of XCD x (blockIdx mod 8) take from head x first: the
+             * XCD's L2 then serves rays from one eighth of the image.  A band that is used up is followed by the band
+             * with the most chunks left.  Every chunk id is handed out exactly once whatever the bands really contain
+             * (the mapping band, j -> c is a bijection onto the chunk ids), so affinity is only ever a hint. */
+            while (chunk_next >= chunk_end && W.affine && !drained) {            /* wave-uniform */
+                const uint32_t lo = (uint32_t)(((unsigned long long)band * af_cps + 7u) >> 3);
+                const uint32_t n_x = (uint32_t)((((unsigned long long)band + 1u) * af_cps + 7u) >> 3) - lo;
+                uint32_t j = 0;
+                if (lane == 0) j = atomicAdd(&W.count[WF_HEAD_WORDS * (1 + band)], 1u);
+                j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
+                const uint32_t seg = n_x ? j / n_x : af_chunks;
+                const unsigned long long c = (unsigned long long)seg * af_cps + lo + (n_x ? j - seg * n_x : 0u);
+                if (n_x && c < af_chunks) {
+                    chunk_next = (uint32_t)c * chunk;
+                    chunk_end = chunk_next + chunk < n_queue ? chunk_next + chunk : n_queue;
+                } else {
+                    /* this band is used up: go on with the one that has the most chunks left */
+                    uint32_t most = 0u;
+                    int where = -1;
+                    for (int x = 0; x < 8; ++x) {
+                        const uint32_t xlo = (uint32_t)(((unsigned long long)x * af_cps + 7u) >> 3);
+                        const uint32_t xn = (uint32_t)((((unsigned long long)x + 1u) * af_cps + 7u) >> 3) - xlo;
+                        const uint32_t full = af_chunks / af_cps, rest = af_chunks - full * af_cps;
+                        const uint32_t total = full * xn + (rest > xlo ? (rest - xlo < xn ? rest - xlo : xn) : 0u);
+                        const uint32_t hd = __hip_atomic_load(&W.count[WF_HEAD_WORDS * (1 + x)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t left = total > hd ? total - hd : 0u;
+                        if (left > most) { most = left; where = x; }
+                    }
+                    where = __builtin_amdgcn_readfirstlane(where);
+                    if (where < 0 || ++band_tried > 32) { drained = true; chunk_next = chunk_end = n_queue; }
+                    else band = where;
+                }
             }
             const uint32_t base = chunk_next;
             const uint32_t avail = chunk_end - chunk_next;
@@ -402,13 +447,17 @@ __device__ __forceinline__ bool wf_logic_one(const DScene& S, const WfState& W, 
     return alive;
 }
 
-/* A block runs WF_LOGIC_TILES consecutive tiles of 256 queue entries and appends its survivors to the next queue with
- * ONE atomic, in entry order (so the queue stays sorted by slot and the state accesses stay nearly coalesced).  With
- * one atomic per wave the kernel was bound by that single word: 7.3 M returning atomics per call of the 1M-triangle
- * bench at the ~90 M/s a word sustains is 81 of its 86 ms. */
+/* The queue stays in SLOT ORDER from iteration to iteration.  A logic block runs WF_LOGIC_TILES consecutive tiles of
+ * 256 queue entries, moves its survivors to the front of its own span of the queue, in entry order, and leaves their
+ * number in scan[block]; wf_scan_kernel (one block) turns the numbers into offsets and wf_move_kernel copies every
+ * span to its place in the other queue.  No atomics, and a position in the queue keeps saying where in the frame its
+ * slot is.  (The first version appended each block's survivors to the other queue with one atomic per block, in the
+ * order in which the blocks happened to finish: over hundreds of iterations the queue drifted away from slot order,
+ * the state accesses lost their coalescing, and calls had to be cut into parts that rebuilt the queue.) */
 #ifndef WF_LOGIC_TILES
 #define WF_LOGIC_TILES 4
 #endif
+#define WF_SPAN (RT_BLOCK * WF_LOGIC_TILES)
 template <uint32_t F, int BG>
 __global__ __launch_bounds__(RT_BLOCK) void wf_logic_kernel(DScene S, WfState W, int qi, int Wd, int Hd, uint32_t s_end,
                                                             uint32_t k0, uint32_t k1, int max_depth)
@@ -416,16 +465,16 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_logic_kernel(DScene S, WfState W,
     __shared__ int slot_mem[RT_BLOCK];
     __shared__ uint32_t keep_slot[WF_LOGIC_TILES][RT_BLOCK];
     __shared__ unsigned long long keep_mask[WF_LOGIC_TILES][RT_BLOCK / 64];
-    __shared__ uint32_t base_s;
     int* slots = slot_mem + (threadIdx.x & ~63u);
     const uint32_t n_queue = W.count[qi];
-    const uint32_t first = blockIdx.x * (RT_BLOCK * WF_LOGIC_TILES);
+    const uint32_t first = blockIdx.x * WF_SPAN;
     if (first >= n_queue) return;                             /* whole block beyond the queue */
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    uint32_t* __restrict__ queue = W.queue[qi];
     for (int tile = 0; tile < WF_LOGIC_TILES; ++tile) {
         const uint32_t e = first + tile * RT_BLOCK + threadIdx.x;
         const bool active = e < n_queue;
-        const uint32_t slot = active ? W.queue[qi][e] : 0u;
+        const uint32_t slot = active ? queue[e] : 0u;
         bool alive = false;
         if (first + tile * RT_BLOCK < n_queue)                /* block-uniform: skip tiles beyond the queue */
             alive = wf_logic_one<F, BG>(S, W, active, slot, Wd, Hd, s_end, k0, k1, max_depth, slots);
@@ -433,27 +482,55 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_logic_kernel(DScene S, WfState W,
         const unsigned long long m = __ballot(alive);
         if (lane == 0) keep_mask[tile][wave] = m;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t total = 0;
-        for (int t = 0; t < WF_LOGIC_TILES; ++t)
-            for (int w = 0; w < RT_BLOCK / 64; ++w) total += (uint32_t)__popcll(keep_mask[t][w]);
-        base_s = total ? atomicAdd(&W.count[qi ^ 1], total) : 0u;
-    }
-    __syncthreads();
-    uint32_t* __restrict__ out = W.queue[qi ^ 1];
-    uint32_t before = base_s;                                 /* survivors of earlier (tile, wave) pairs */
+    __syncthreads();                                          /* every entry of the span has been read */
+    uint32_t before = 0;                                      /* survivors of earlier (tile, wave) pairs */
     for (int t = 0; t < WF_LOGIC_TILES; ++t)
         for (int w = 0; w < RT_BLOCK / 64; ++w) {
             const unsigned long long m = keep_mask[t][w];
             if (w == wave && ((m >> lane) & 1ull)) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                out[before + rank] = keep_slot[t][threadIdx.x];
+                queue[first + before + rank] = keep_slot[t][threadIdx.x];
             }
             before += (uint32_t)__popcll(m);
         }
+    if (threadIdx.x == 0) W.scan[blockIdx.x] = before;
 }
 
+/* One block.  scan[0 .. n) holds the survivors of the n spans of queue[qi]; afterwards scan[b] is where span b's
+ * survivors start in the other queue, scan[n] and count[qi ^ 1] their total.  Also rewinds the intersect kernel's fetch
+ * heads for the next iteration. */
+__global__ __launch_bounds__(1024) void wf_scan_kernel(WfState W, int qi)
+{
+    __shared__ uint32_t sums[1024];
+    const uint32_t n_queue = W.count[qi];
+    const uint32_t n = (n_queue + WF_SPAN - 1) / WF_SPAN;
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t b0 = threadIdx.x * per < n ? threadIdx.x * per : n, b1 = b0 + per < n ? b0 + per : n;
+    uint32_t mine = 0;
+    for (uint32_t b = b0; b < b1; ++b) mine += W.scan[b];
+    sums[threadIdx.x] = mine;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {          /* Hillis-Steele inclusive scan */
+        const uint32_t v = threadIdx.x >= off ? sums[threadIdx.x - off] : 0u;
+        __syncthreads();
+        sums[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = sums[threadIdx.x] - mine;                  /* exclusive prefix of this thread's range */
+    for (uint32_t b = b0; b < b1; ++b) { const uint32_t v = W.scan[b]; W.scan[b] = run; run += v; }
+    if (threadIdx.x == 1023u) { W.scan[n] = sums[1023]; W.count[qi ^ 1] = sums[1023]; W.count[2] = 0u; }
+    if (threadIdx.x < 8) W.count[WF_HEAD_WORDS * (1 + threadIdx.x)] = 0u;     /* the bands' fetch heads */
+}
+__global__ __launch_bounds__(RT_BLOCK) void wf_move_kernel(WfState W, int qi)
+{
+    const uint32_t n_queue = W.count[qi];
+    const uint32_t first = blockIdx.x * WF_SPAN;
+    if (first >= n_queue) return;
+    const uint32_t to = W.scan[blockIdx.x], n = W.scan[blockIdx.x + 1] - to;
+    const uint32_t* __restrict__ in = W.queue[qi] + first;
+    uint32_t* __restrict__ out = W.queue[qi ^ 1] + to;
+    for (uint32_t i = threadIdx.x; i < n; i += RT_BLOCK) out[i] = in[i];
+}
 
 /* accum[pixel] += the K stream sums of the pixel, in stream order */
 __global__ __launch_bounds__(RT_BLOCK) void wf_finalize_kernel(WfState W, float* __restrict__ accum)
