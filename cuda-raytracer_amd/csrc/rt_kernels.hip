@@ -750,17 +750,12 @@ template <uint32_t V>
 static int wf_run_part(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t s1, uint32_t k0, uint32_t k1, int max_depth,
                        int background, float* accum);
 
-/* A slot runs its samples one after the other, and the queue is written afresh in every iteration in the order in which
- * the logic kernel's blocks happen to finish: over hundreds of iterations the queue drifts away from slot order and
- * the state accesses lose their coalescing.  Measured on the final scene at 3840x2160 (16 streams per pixel), 512 spp
- * rendered as one part / parts of 256 / 128 / 64 samples: 3.48 / 3.56 / 3.62 / 3.67 Grays/s; all 4096 spp as one part: 3.14.
- * Each part starts from a queue in slot order, but also ends with a drain, so parts of one sample per stream lose
- * again (1M triangles, 64 streams: 256 spp as one part 2.72, as four parts 2.62).  A call is therefore cut into parts
- * of FOUR samples per stream.  A call with a single stream per pixel is left whole: it then sums a pixel's samples in
- * the megakernel's order and has its bits (tests/test_gpu_parity.py). */
-#ifndef WF_PART_SAMPLES
-#define WF_PART_SAMPLES 4
-#endif
+/* A call is normally ONE part.  While the queue was appended to in the order in which the logic kernel's blocks happened
+ * to finish, it drifted away from slot order over hundreds of iterations and long calls were cut into parts of four
+ * samples per stream, each starting from a fresh queue (final scene 3840x2160 x 4096 spp as one call: 3.14 Grays/s whole,
+ * 3.68 in parts).  Since the queue keeps slot order by construction (rt_wavefront.h, wf_logic_kernel) the parts only add
+ * drains: 512 spp of that scene 3.88 whole against 3.80 in parts.  RT_WF_PART = samples per part remains as a
+ * measurement switch (0 or unset = whole). */
 template <uint32_t V>
 static int wf_run(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t s1, uint32_t k0, uint32_t k1, int max_depth,
                   int background, float* accum)
@@ -768,9 +763,9 @@ static int wf_run(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t s1, u
     const size_t n_pixels = (size_t)win.z * (size_t)win.w;
     size_t streams = (c->wf_slots_target + n_pixels - 1) / n_pixels;       /* what wf_run_part will settle on, or a little more */
     if (streams > s1 - s0) streams = s1 - s0;
-    unsigned long long part = (unsigned long long)WF_PART_SAMPLES * (streams < 1 ? 1 : streams);
-    if (const char* e = std::getenv("RT_WF_PART")) { const long long v = std::atoll(e); if (v > 0) part = (unsigned long long)v; else part = ~0ull; }
-    if (streams <= 1 || (unsigned long long)(s1 - s0) <= part + part / 2) return wf_run_part<V>(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum);
+    unsigned long long part = ~0ull;
+    if (const char* e = std::getenv("RT_WF_PART")) { const long long v = std::atoll(e); if (v > 0) part = (unsigned long long)v; }
+    if (streams <= 1 || part == ~0ull || (unsigned long long)(s1 - s0) <= part + part / 2) return wf_run_part<V>(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum);
     for (unsigned long long a = s0; a < s1; a += part) {
         const uint32_t b = a + part < s1 ? (uint32_t)(a + part) : s1;
         int rc = wf_run_part<V>(c, w, h, win, (uint32_t)a, b, k0, k1, max_depth, background, accum);

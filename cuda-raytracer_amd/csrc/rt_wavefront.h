@@ -137,7 +137,7 @@ __global__ __launch_bounds__(RT_BLOCK, wf_intersect_waves(F)) void wf_intersect_
     af_cps = af_cps < 8u ? 8u : af_cps;
     int band = (int)(blockIdx.x & 7u), band_tried = 0;
 #ifdef RT_STAMPS
-    unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* trips, busy lanes, node, prim, -, -, with prim, cycles */
+    unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* trips, busy lanes, node, prim, stalled lanes, trips with a node step, trips with a prim step, cycles */
     const unsigned long long dg_t0 = __builtin_amdgcn_s_memtime();
 #endif
 
@@ -240,6 +240,8 @@ __global__ __launch_bounds__(RT_BLOCK, wf_intersect_waves(F)) void wf_intersect_
         {
             const int nb = __popcll(__ballot(mode != WF_NEED));
             dg[0] += 1; dg[1] += nb; dg[2] += n_node; dg[3] += do_prim ? n_prim : 0; dg[6] += do_prim ? 1 : 0;
+            dg[4] += __popcll(__ballot(in_bvh && !interior && !prim_step));      /* lanes with a ray and nothing to do this trip */
+            dg[5] += n_node > 0 ? 1 : 0;
         }
 #endif
         /* the loads of both steps of the trip go out together */
