@@ -28,6 +28,9 @@ F_RECT, F_SPHERE, F_TRI, F_NODE, F_ROT, F_TRANS = 15.0, 30.0, 105.0, 50.0, 12.0,
 F_SHADE, F_SPHERE_ITER, F_PHILOX = 60.0, 20.0, 100.0
 PEAK_VALU_TFLOPS = 157.3   # MI355X fp32 vector peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0      # HBM3E spec peak
+N_CUS = 256
+CLOCK_GHZ = 2.4
+TA_LANES_PER_CLOCK = 1.0       # divergent 16-byte lane loads a CU's address unit takes per clock, measured (profiles/r02_gather_sizes.jsonl)
 L2_MISS_REQUESTS_PEAK = 58.0   # G random 64-B / 128-B row requests per second that leave the L2s, measured (profiles/r02_gather_rates.jsonl)
 
 WORKLOADS = {
@@ -239,12 +242,14 @@ def main():
         # roofline of the dominant kernel, duration from HIP events recorded on its own stream inside the library.
         # megakernel: render_kernel is the launch, bound by VALU issue (its tables sit in the scalar cache).
         # wavefront: the event pair spans the whole intersect/logic loop (the pools' kernels overlap, so per-kernel
-        # durations of a trace add up to more than the call).  What bounds it is the rate at which the L2s can send
-        # MISSES to the fabric: tools/ubench/gather.hip measures 58 G random row requests/s chip-wide on this part for
-        # 64-B and for 128-B rows alike, from a 110 MB table (Infinity Cache) and from a 1 GB one (HBM) alike.  The
-        # intersect kernel fetches one 128-B row per 4-wide node step and one 64-B row per leaf primitive (counted by
-        # the diagnostic build, tools/stamps.py); the L2 hit rate comes from the committed PMC pass.  The algorithmic
-        # HBM-bytes fraction SURVEY 8(d) defines is carried under "hbm_algorithmic"; it is not what binds.
+        # durations of a trace add up to more than the call).  Three limits sit close together on that loop and all
+        # three are reported under "limits" (DESIGN.md section 6): VALU issue of the intersect kernel (PMC pass), the
+        # rate at which a CU's address unit takes divergent 16-byte lane loads (tools/ubench/gather.hip with an
+        # L2-resident table: about one lane per clock per CU), and the rate at which L2 misses leave the L2s (same
+        # ubench, 110 MB and 1 GB tables: 58 G row requests/s chip-wide).  The line's own bound is the tightest one,
+        # VALU issue, stated like the megakernel's: algorithmic flops per ray against the fp32 vector
+        # peak.  The algorithmic HBM-bytes fraction SURVEY 8(d) defines is carried under "hbm_algorithmic"; the BVH
+        # sits in the Infinity Cache and HBM bandwidth does not bind.
         rays_per_launch = rays / world / max(1, c.render_launches)
         kname = "wf_intersect_kernel + wf_logic_kernel loop" if wavefront else "render_kernel"
         pm = None
@@ -254,29 +259,39 @@ def main():
                 pm = json.load(open(tpath)).get(out["config"]["workload"])
             except Exception:
                 pm = None
-        roof = {"bound": "l2-miss-requests" if wavefront else "valu", "kernel": kname, "kernel_ms": kernel_ms,
-                "peak": L2_MISS_REQUESTS_PEAK if wavefront else PEAK_VALU_TFLOPS, "unit": "Grequests/s" if wavefront else "TFLOP/s",
+        roof = {"bound": "valu", "kernel": kname, "kernel_ms": kernel_ms, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
                 "achieved": None, "frac": None, "traffic": None}
         if base_stats is not None and kernel_ms > 0:
             fpr = flops_per_ray(base_stats)
             bpr = bytes_per_ray(base_stats, W, H, spp, scene_bytes, wavefront)
             ach_f = rays_per_launch * fpr / (kernel_ms * 1e-3) / 1e12
             ach_b = rays_per_launch * bpr / (kernel_ms * 1e-3) / 1e9
+            roof.update({"achieved": ach_f, "frac": ach_f / PEAK_VALU_TFLOPS, "flops_per_ray": fpr})
             if wavefront:
                 rows = (pm or {}).get("rows_per_ray")
                 hit = (pm or {}).get("l2_hit_rate")
-                if rows and hit is not None:
-                    per_ray = rows["node4_128B"] + rows["leaf_64B"] + rows["state_64B"]
-                    ach = rays_per_launch * per_ray * (1.0 - hit) / (kernel_ms * 1e-3) / 1e9
-                    roof.update({"achieved": ach, "frac": ach / L2_MISS_REQUESTS_PEAK, "row_requests_per_ray": per_ray, "l2_hit_rate": hit})
+                limits = {"valu_issue_intersect": {"busy": (pm or {}).get("valu_busy"), "lane_efficiency": (pm or {}).get("lane_efficiency"),
+                                                   "source": "profiles/pmc_summary.json (rocprofv3 --pmc pass of this command)"}}
+                if rows:
+                    rays_s = rays_per_launch / (kernel_ms * 1e-3)
+                    # 16-byte lane loads and stores per ray: 7 per four-wide node row, 4 per leaf row, and the path
+                    # state (refill 2 + hit 1 in the intersect kernel; 5 loads + 4 stores in the logic kernel)
+                    lane_ops = 7.0 * rows["node4_128B"] + 4.0 * rows["leaf_64B"] + 12.0
+                    per_clk_cu = rays_s * lane_ops / (N_CUS * CLOCK_GHZ * 1e9)
+                    limits["vector_memory_address_rate"] = {
+                        "lane_16B_accesses_per_ray": lane_ops, "achieved_per_clock_per_CU": per_clk_cu, "peak_per_clock_per_CU": TA_LANES_PER_CLOCK,
+                        "frac": per_clk_cu / TA_LANES_PER_CLOCK,
+                        "source": "profiles/r02_gather_sizes.jsonl: L2-resident random rows, 76 G x 7 and 174 G x 4 lane loads/s = 0.87 and 1.13 per clock per CU"}
+                    if hit is not None:
+                        per_ray = rows["node4_128B"] + rows["leaf_64B"] + rows["state_64B"]
+                        ach = rays_s * per_ray * (1.0 - hit) / 1e9
+                        limits["l2_miss_requests"] = {"achieved_Grequests_per_s": ach, "peak_Grequests_per_s": L2_MISS_REQUESTS_PEAK,
+                                                      "frac": ach / L2_MISS_REQUESTS_PEAK, "row_requests_per_ray": per_ray, "l2_hit_rate": hit,
+                                                      "source": "profiles/r02_gather_rates.jsonl (110 MB and 1 GB tables)"}
+                roof["limits"] = limits
                 roof["hbm_algorithmic"] = {"bytes_per_ray": bpr, "achieved_GBs": ach_b, "peak_GBs": PEAK_HBM_GBS, "frac": ach_b / PEAK_HBM_GBS,
                                            "note": "SURVEY 8(d) formula; the BVH sits in the Infinity Cache, HBM bandwidth does not bind"}
-                roof["l3_gather_peak"] = {"Grequests_per_s": L2_MISS_REQUESTS_PEAK, "TB_per_s_at_128B_rows": 6.6, "TB_per_s_at_64B_rows": 3.7,
-                                          "source": "profiles/r02_gather_rates.jsonl (tools/ubench/gather.hip)"}
             else:
-                roof.update({"achieved": ach_f, "frac": ach_f / PEAK_VALU_TFLOPS})
-            roof.update({"flops_per_ray": fpr, "valu_peak_TFLOPs": PEAK_VALU_TFLOPS, "valu_achieved_TFLOPs": ach_f, "valu_frac": ach_f / PEAK_VALU_TFLOPS})
-            if not wavefront:
                 roof.update({"bytes_per_ray": bpr, "hbm_peak_GBs": PEAK_HBM_GBS, "hbm_achieved_GBs": ach_b, "hbm_frac": ach_b / PEAK_HBM_GBS})
         # counters cannot be read in-process: the per-call HBM bytes and the PMC-derived shares come from the
         # committed rocprofv3 passes of this same command (tools/prof_round.sh -> profiles/pmc_summary.json), which

@@ -25,7 +25,7 @@ B.lib().rt_debug_stamps(ctx.handle, out)
 for q in range(6, 10):
     out[q] -= base[q]      # the device-global loop counters are not reset with the context's
 if os.environ.get("RT_INTEGRATOR") == "2" or (sc.flat.contents.n_bvh_nodes > 0 and os.environ.get("RT_INTEGRATOR") != "1"):
-    d = [float(out[q] - base[q]) for q in range(8)]
+    d = [float(out[q] - (base[q] if q < 6 else 0)) for q in range(8)]      # 6..9 already had their base taken off above
     print("%s %dx%d@%d wavefront: %.1f ms, %.1f Mrays/s, rays %d" % (name, W, H, spp, c.last_render_ms, c.rays / c.last_render_ms / 1e3, c.rays))
     print("  intersect: %.1f trips per ray-lane (trips*64/rays), busy lanes/trip %.1f, node lanes %.1f, prim lanes %.1f"
           % (d[0] * 64 / c.rays, d[1] / d[0], d[2] / d[0], d[3] / d[0]))
