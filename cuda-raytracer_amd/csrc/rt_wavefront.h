@@ -145,6 +145,10 @@ __global__ __launch_bounds__(RT_BLOCK, wf_intersect_waves(F)) void wf_intersect_
         /* ---- refill: lanes without a ray take the next queue entries, a wave-wide batch at a time ---- */
         const unsigned long long need = __ballot(mode == WF_NEED);
         const int n_need = __popcll(need);
+#ifdef RT_STAMPS_REFILL
+        const bool rf_on = !drained && (n_need >= W.refill_min || n_need == 64);
+        const unsigned long long rf_t0 = __builtin_amdgcn_s_memtime();
+#endif
         if (!drained && (n_need >= W.refill_min || n_need == 64)) {
             /* The wave owns a chunk [chunk_next, chunk_end) of the queue and hands its entries to idle
              * lanes; one returning atomic on the shared head per WF_CHUNK rays (a single word sustains
@@ -217,6 +221,9 @@ __global__ __launch_bounds__(RT_BLOCK, wf_intersect_waves(F)) void wf_intersect_
                 }
             }
         }
+#ifdef RT_STAMPS_REFILL
+        if (rf_on) { dg[4] += __builtin_amdgcn_s_memtime() - rf_t0; dg[5] += 1; }      /* cycles inside refills, refills (instead of stalled lanes, node trips) */
+#endif
         if (__ballot(mode != WF_NEED) == 0ull) {
             if (drained) break;
             continue;                            /* a batch that finished at once (no BVH group), or all 64 lanes idle */
@@ -240,8 +247,10 @@ __global__ __launch_bounds__(RT_BLOCK, wf_intersect_waves(F)) void wf_intersect_
         {
             const int nb = __popcll(__ballot(mode != WF_NEED));
             dg[0] += 1; dg[1] += nb; dg[2] += n_node; dg[3] += do_prim ? n_prim : 0; dg[6] += do_prim ? 1 : 0;
+#ifndef RT_STAMPS_REFILL
             dg[4] += __popcll(__ballot(in_bvh && !interior && !prim_step));      /* lanes with a ray and nothing to do this trip */
             dg[5] += n_node > 0 ? 1 : 0;
+#endif
         }
 #endif
         /* the loads of both steps of the trip go out together */
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(RT_BLOCK, wf_intersect_waves(F)) void wf_intersect_
     if (lane == 0) atomicAdd(&counters[0], r);
 #ifdef RT_STAMPS
     dg[7] = __builtin_amdgcn_s_memtime() - dg_t0;
-    if (lane == 0) for (int q = 0; q < 8; ++q) atomicAdd(&counters[4 + q], dg[q]);
+    if (lane == 0) for (int q = 0; q < 8; ++q) atomicAdd(&counters[4 + (q < 6 ? q : q + 4)], dg[q]);     /* rt_debug_stamps overlays words 6..9 */
 #endif
 }
 

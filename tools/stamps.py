@@ -25,12 +25,16 @@ B.lib().rt_debug_stamps(ctx.handle, out)
 for q in range(6, 10):
     out[q] -= base[q]      # the device-global loop counters are not reset with the context's
 if os.environ.get("RT_INTEGRATOR") == "2" or (sc.flat.contents.n_bvh_nodes > 0 and os.environ.get("RT_INTEGRATOR") != "1"):
-    d = [float(out[q] - (base[q] if q < 6 else 0)) for q in range(8)]      # 6..9 already had their base taken off above
+    d = [float(out[q] - base[q]) for q in (0, 1, 2, 3, 4, 5, 10, 11)]      # the intersect kernel's eight counters
     print("%s %dx%d@%d wavefront: %.1f ms, %.1f Mrays/s, rays %d" % (name, W, H, spp, c.last_render_ms, c.rays / c.last_render_ms / 1e3, c.rays))
     print("  intersect: %.1f trips per ray-lane (trips*64/rays), busy lanes/trip %.1f, node lanes %.1f, prim lanes %.1f"
           % (d[0] * 64 / c.rays, d[1] / d[0], d[2] / d[0], d[3] / d[0]))
-    print("  trips with a node step %.3f (%.1f lanes each), with a primitive step %.3f (%.1f lanes each); stalled lanes/trip %.1f; cycles/trip %.0f"
-          % (d[5] / d[0], d[2] / max(1.0, d[5]), d[6] / d[0], d[3] / max(1.0, d[6]), d[4] / d[0], d[7] / d[0]))
+    if os.environ.get("RT_STAMPS_REFILL"):      # library built with `make stamps STAMPS_EXTRA=-DRT_STAMPS_REFILL`: words 4, 5 = cycles inside refills, refills
+        print("  refills per trip %.3f, %.0f cycles each, %.1f %% of the kernel's cycles; trips with a primitive step %.3f (%.1f lanes each); cycles/trip %.0f"
+              % (d[5] / d[0], d[4] / max(1.0, d[5]), 100.0 * d[4] / max(1.0, d[7]), d[6] / d[0], d[3] / max(1.0, d[6]), d[7] / d[0]))
+    else:
+        print("  trips with a node step %.3f (%.1f lanes each), with a primitive step %.3f (%.1f lanes each); stalled lanes/trip %.1f; cycles/trip %.0f"
+              % (d[5] / d[0], d[2] / max(1.0, d[5]), d[6] / d[0], d[3] / max(1.0, d[6]), d[4] / d[0], d[7] / d[0]))
     print("  rows fetched per ray: %.2f four-wide nodes (128-B rows) + %.2f leaf primitives (64-B rows)" % (d[2] / c.rays, d[3] / c.rays))
     sys.exit(0)
 names = ["regen", "closest_hit", "rebuild", "ball", "tail", "scatter+rest"]
