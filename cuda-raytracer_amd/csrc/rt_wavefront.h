@@ -71,7 +71,10 @@ enum { WF_NEED = 0, WF_BVH = 2 };
 #ifndef WF_GENERAL_WAVES
 #define WF_GENERAL_WAVES 4
 #endif
-constexpr int wf_intersect_waves(uint32_t F) { return (F & ~(RT_F_BVH | RT_F_TRI | RT_F_PLANAR)) == 0 ? 5 : WF_GENERAL_WAVES; }
+#ifndef WF_TRI_WAVES
+#define WF_TRI_WAVES 5
+#endif
+constexpr int wf_intersect_waves(uint32_t F) { return (F & ~(RT_F_BVH | RT_F_TRI | RT_F_PLANAR)) == 0 ? WF_TRI_WAVES : WF_GENERAL_WAVES; }
 #define WF_HEAD_WORDS 32     /* a band's fetch head sits on a 128-B line of its own: count[32 (1 + band)] */
 #define WF_LDS_STACK 20      /* traversal-stack entries per lane kept in LDS; deeper ones go to scratch */
 #define WF_OVF_STACK 44      /* entries of the scratch overflow: 3 per level of a 4-wide tree, rarely reached */
@@ -257,12 +260,14 @@ __global__ __launch_bounds__(RT_BLOCK, wf_intersect_waves(F)) void wf_intersect_
         const int lfirst = (~pleaf) >> 4, lcount = ((~pleaf) & 15) + 1;
         const float4* nsrc = reinterpret_cast<const float4*>(S.nodes4 + (interior ? ref : 0));
         const float4* src = reinterpret_cast<const float4*>(S.leafs + (prim_step ? lfirst + li : 0));
-        float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0, n3 = n0, n4 = n0, n5 = n0, n6 = n0;
-        float4 q0 = n0, q1 = n0, q2 = n0, q3 = n0;
-        if (interior) { n0 = nsrc[0]; n1 = nsrc[1]; n2 = nsrc[2]; n3 = nsrc[3]; n4 = nsrc[4]; n5 = nsrc[5]; n6 = nsrc[6]; }
+        /* the leaf row first (zero-filled where no primitive step runs: leaving the registers undefined there made the
+         * allocator spill, final scene 3.72 -> 2.65 Grays/s), then the node row inside the node step's own block, which
+         * needs no fill at all */
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0, q3 = q0;
         if (prim_step) { q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3]; }
 
         if (interior) {
+            const float4 n0 = nsrc[0], n1 = nsrc[1], n2 = nsrc[2], n3 = nsrc[3], n4 = nsrc[4], n5 = nsrc[5], n6 = nsrc[6];
             const float b0[6] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y}, b1[6] = {n1.z, n1.w, n2.x, n2.y, n2.z, n2.w};
             const float b2[6] = {n3.x, n3.y, n3.z, n3.w, n4.x, n4.y}, b3[6] = {n4.z, n4.w, n5.x, n5.y, n5.z, n5.w};
             int r0 = __float_as_int(n6.x), r1 = __float_as_int(n6.y), r2 = __float_as_int(n6.z), r3 = __float_as_int(n6.w);
@@ -291,6 +296,13 @@ __global__ __launch_bounds__(RT_BLOCK, wf_intersect_waves(F)) void wf_intersect_
             bool h;
             if (!(F & RT_F_XFORM) || obj_op_count(head) == 0) h = prim_t<F>(obj_type(head), f, rl, tMin, best.t, t, aux);
             else h = leaf_t<F>(S, S.objs[oi], rl, tMin, best.t, t, aux);
+            /* word 1 of the row (the material index, never a NaN pattern) is not needed here, but with a hole at word 1 the
+             * compiler fetches the row as dword + 3 x dwordx4 at offsets 8, 24, 40 + dwordx2: five lane loads, three of them
+             * misaligned, in a kernel whose trips last as long as their lane loads.  Comparing the word with itself as a
+             * float cannot be folded away, so the row arrives as four aligned dwordx4. */
+#ifndef WF_LEAF_NARROW
+            h = h && q0.y == q0.y;
+#endif
             if (h) { best.t = t; best.obj = oi; best.grp = gi; best.aux = aux; }
             if (++li == lcount) { li = 0; pleaf = RT_REF_NONE; }
         }
