@@ -100,7 +100,8 @@ __global__ __launch_bounds__(RT_BLOCK, wf_intersect_waves(F)) void wf_intersect_
 
     int mode = WF_NEED;
     uint32_t slot = 0;
-    DRay rw = {mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f), 0.f}, rl = rw;
+    DRay rw = {mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f), 0.f}, rl_own = rw;
+    DRay& rl = (F & RT_F_XFORM) ? rl_own : rw;      /* the ray in the group's frame: the world ray itself where no scene object is wrapped */
     V3 id = mk(0.f, 0.f, 0.f);
     HitLite best = {FLT_MAX, -1, -1, 0};
     int gidx = 0, gi = -1, ref = RT_REF_NONE, pleaf = RT_REF_NONE, sp = 0, li = 0;
@@ -114,8 +115,7 @@ __global__ __launch_bounds__(RT_BLOCK, wf_intersect_waves(F)) void wf_intersect_
         if (gidx < W.n_groups) {                                                                                 \
             const int obj_ = W.groups[gidx];                                                                     \
             const DObj& o_ = S.objs[obj_];                                                                       \
-            rl = rw;                                                                                             \
-            if (F & RT_F_XFORM) apply_chain(S, o_, rl);                                                          \
+            if (F & RT_F_XFORM) { rl = rw; apply_chain(S, o_, rl); }                                             \
             id = mk(1.f / rl.d.x, 1.f / rl.d.y, 1.f / rl.d.z);                                                   \
             mode = WF_BVH; gi = obj_ == S.world ? -1 : obj_; ref = o_.pad[0]; pleaf = RT_REF_NONE; sp = 0; li = 0; \
         } else {                                                                                                 \
