@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--full", action="store_true", help="also the 128x72 primary-hit maps of tri_mesh at 1,000,000 triangles and "
                     "final at 100 x 100 boxes, from the reference's flat HitableList (minutes)")
     ap.add_argument("--full-only", action="store_true", help="only those")
+    ap.add_argument("--special-only", action="store_true", help="only geom_special_ref.npz: rays with zero / negative-zero / huge / tiny "
+                    "direction components, origins on surfaces, rays through box corners and triangle vertices")
     args = ap.parse_args()
     b = entry.load_binding()
     o = entry.load_oracle()
@@ -91,6 +93,9 @@ def main():
         return
     if args.full_only:
         make_full(b, ref, orc)
+        return
+    if args.special_only:
+        make_special(b, ref, orc)
         return
     rng = np.random.default_rng(20261110)
 
@@ -195,6 +200,7 @@ def main():
 
     if args.full:
         make_full(b, ref, orc)
+    make_special(b, ref, orc)
     make_images(args, b, orc)
 
 
@@ -207,6 +213,105 @@ def primary_rays(cam, w, h):
     d = ((ll + u[..., None] * hz).astype(np.float32) + v[..., None] * vt).astype(np.float32) - og
     return np.concatenate([np.broadcast_to(og, d.shape), d.astype(np.float32), np.full(d.shape[:2] + (1,), cam.time0, np.float32)],
                           axis=2).reshape(-1, 7)
+
+
+SPECIAL_SCENES = [("kat", 0), ("cornell", 0), ("bvh_boxes", 0), ("tri_mesh", 800), ("cornell_cluster", 0)]
+
+
+SPECIAL_KINDS = ("corner", "axis_on_surface", "axis_offset", "in_plane", "scaled", "far")
+
+
+def special_rays(flat, rng):
+    """Rays the random draws of section 1 never produce: where a division's divisor is +-0, a product is 0 * inf, a hit lies
+    exactly on an edge, a corner or the tMin / tMax bound, or the operands sit at the ends of the float range.  Returns
+    the rays and their kind (index into SPECIAL_KINDS):
+      corner           from the camera exactly at box corners / centres (edges, vertices, shared faces)
+      axis_on_surface  along the axes and the face diagonals (zero and negative-zero components) from those same points:
+                       the origin lies ON bounding planes, so 0 / 0 and 0 * inf occur
+      axis_offset      the same directions from origins moved off those planes by a random amount: divisors of +-0
+                       without 0 / 0
+      in_plane         along z from the camera's side, inside face planes
+      scaled           `corner` with the direction scaled by 1e18, 1e-18, 1e-30 (same line, t scales)
+      far              `corner` with the origin moved 1e5 direction lengths back (coordinates of 1e7 and more: what is left of
+                       float precision there decides, and culling by boxes decides differently from the primitives)"""
+    f = flat.contents
+    cam = f.camera
+    og = np.array(cam.origin[:], np.float32)
+    corners = []
+    for i in range(f.n_objects):
+        o = f.objects[i]
+        if o.prim_id < 0:
+            continue
+        lo, hi = np.array(o.bmin[:], np.float32), np.array(o.bmax[:], np.float32)
+        if not (np.isfinite(lo).all() and np.isfinite(hi).all()):
+            continue
+        for m in range(8):
+            corners.append(np.where([(m >> k) & 1 for k in range(3)], hi, lo))
+        corners.append((0.5 * (lo.astype(np.float64) + hi)).astype(np.float32))
+    corners = np.unique(np.array(corners, np.float32), axis=0)
+    if len(corners) > 160:
+        corners = corners[np.sort(rng.choice(len(corners), 160, replace=False))]
+    out, kinds = [], []
+
+    def add(rays, kind):
+        out.append(np.asarray(rays, np.float32))
+        kinds.append(np.full(len(rays), SPECIAL_KINDS.index(kind), np.int32))
+
+    a = np.concatenate([np.tile(og, (len(corners), 1)), corners - og], axis=1)
+    add(a, "corner")
+    dirs = []
+    for ax in range(3):
+        for sgn in (1.0, -1.0):
+            e = np.zeros(3, np.float32); e[ax] = sgn
+            dirs.append(e)
+            e2 = e.copy(); e2[(ax + 1) % 3] = -0.0      # a negative zero beside it
+            dirs.append(e2)
+    for ax in range(3):
+        for s1 in (1.0, -1.0):
+            for s2 in (1.0, -1.0):
+                e = np.zeros(3, np.float32); e[ax] = s1; e[(ax + 1) % 3] = s2
+                dirs.append(e)
+    dirs = np.array(dirs, np.float32)
+    some = corners[:: max(1, len(corners) // 24)]
+    add(np.concatenate([np.repeat(some, len(dirs), axis=0), np.tile(dirs, (len(some), 1))], axis=1), "axis_on_surface")
+    ext = float(np.max(corners.max(axis=0) - corners.min(axis=0)))
+    moved = (np.repeat(some, len(dirs), axis=0) + rng.uniform(-0.37, 0.37, size=(len(some) * len(dirs), 3)) * 0.05 * ext).astype(np.float32)
+    add(np.concatenate([moved, np.tile(dirs, (len(some), 1))], axis=1), "axis_offset")
+    far = some.copy(); far[:, 2] = og[2]
+    zdir = np.tile(np.array([0.0, 0.0, 1.0], np.float32) * np.sign(-og[2] if og[2] != 0 else 1.0), (len(far), 1))
+    add(np.concatenate([far, zdir], axis=1), "in_plane")
+    a = a[: min(64, len(a))]
+    for scale in (1e18, 1e-18, 1e-30):
+        b = a.copy(); b[:, 3:6] = (b[:, 3:6].astype(np.float64) * scale).astype(np.float32)
+        add(b, "scaled")
+    b = a.copy(); b[:, 0:3] = (a[:, 0:3].astype(np.float64) - 1e5 * a[:, 3:6]).astype(np.float32)
+    add(b, "far")
+    rays = np.concatenate(out).astype(np.float32)
+    return np.concatenate([rays, np.full((len(rays), 1), cam.time0, np.float32)], axis=1), np.concatenate(kinds)
+
+
+def make_special(b, ref, orc):
+    # ---- 6. special rays (see special_rays) through the reference's flat list, whole world, two (tMin, tMax) windows ----
+    rng = np.random.default_rng(20261111)
+    out = {"produced_by": ref.geom_id, "scenes": np.array([n for n, _ in SPECIAL_SCENES]), "kinds": np.array(SPECIAL_KINDS)}
+    for name, param in SPECIAL_SCENES:
+        sc = b.Scene(name, W, H, param)
+        f = sc.flat.contents
+        rays, kind = special_rays(sc.flat, rng)
+        hits = clean_front_face(sc.flat, ref.object_hit(sc.flat, f.world, rays, 0.001, FLT_MAX))
+        got = orc.trace_rays(sc.flat, rays, 0.001, FLT_MAX)
+        h = hits["hit"] == 1
+        same = np.array_equal(got["hit"], hits["hit"]) and np.array_equal(got["t"][h], hits["t"][h], equal_nan=True)
+        # Rects report a hit with t = NaN when the ray lies in their plane (0 / 0 passes every `<` and `>` test of
+        # Rectangle.cuh:27-33): a quirk of the reference that the flat-list restatement reproduces NaN for NaN
+        print("%-16s special rays %5d  hits %5d  of them with t = NaN %d  restatement==reference (hit, t): %s"
+              % (name, len(rays), int(h.sum()), int(np.isnan(hits["t"][h]).sum()), same))
+        out["digest_" + name] = scene_digest(sc.flat)
+        out["param_" + name] = param
+        out["rays_" + name] = rays
+        out["kind_" + name] = kind
+        out["hits_" + name] = hits
+    np.savez_compressed(os.path.join(GOLD, "geom_special_ref.npz"), **out)
 
 
 def make_full(b, ref, orc):

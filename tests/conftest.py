@@ -60,6 +60,31 @@ def golden_scene(binding, oracle_mod, gold, name):
     return sc
 
 
+SPECIAL_SCENES = ["kat", "cornell", "bvh_boxes", "tri_mesh", "cornell_cluster"]      # tests/golden/geom_special_ref.npz
+
+
+def special_scene(binding, oracle_mod, gold, name):
+    """the scene, rays and reference hits of one entry of geom_special_ref.npz (oracle/gen_golden.py, special_rays)"""
+    assert made_by_reference_geometry(gold["produced_by"]), gold["produced_by"]
+    sc = binding.Scene(name, 128, 72, int(gold["param_" + name]))
+    assert oracle_mod.scene_digest(sc.flat) == str(gold["digest_" + name]), "geom_special_ref.npz is stale for " + name
+    return sc, gold["rays_" + name], gold["hits_" + name]
+
+
+def special_order_free(gold, name):
+    """The special rays whose closest hit does not depend on the order in which the primitives are tested, i.e. the ones a
+    BVH must answer like the reference's flat list.  Left out: (i) rays that can meet 0 / 0 — a zero direction component
+    with the origin on a bounding plane (`axis_on_surface`, `in_plane`, and corner rays that happen to share a
+    coordinate with the camera): a rect in whose plane the ray lies reports a hit with t = NaN (Rectangle.cuh:27-33), and
+    a NaN `closest so far` then accepts or rejects whatever is tested next; (ii) `far`: origins at 1e7 and beyond, where
+    box culling and the primitives' own arithmetic round differently."""
+    kinds = [str(k) for k in gold["kinds"]]
+    kind = gold["kind_" + name]
+    d = gold["rays_" + name][:, 3:6]
+    generic = (d != 0).all(axis=1) & np.isin(kind, [kinds.index("corner"), kinds.index("scaled")])
+    return generic | (kind == kinds.index("axis_offset"))
+
+
 GEOM_SCENES = ["kat", "cornell", "lit_sphere", "bvh_boxes", "random_spheres", "cornell_cluster", "final", "tri_mesh", "final_custom"]
 RECT_TYPES = (2, 3, 4, 5)       # front_face is only defined by the reference for rects and boxes
 MOVING_SPHERE = 1               # u,v are left stale by the reference (Sphere.cuh:91-120)

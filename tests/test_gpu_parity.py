@@ -8,7 +8,8 @@ sphere u,v, checker, Schlick, free-flight) are compared with a tolerance."""
 import numpy as np
 import pytest
 
-from conftest import FLT_MAX, GEOM_SCENES, MOVING_SPHERE, golden_scene, load_golden, prim_types
+from conftest import (FLT_MAX, GEOM_SCENES, MOVING_SPHERE, SPECIAL_SCENES, golden_scene, load_golden, prim_types, special_order_free,
+                      special_scene)
 
 pytestmark = pytest.mark.gpu
 
@@ -48,6 +49,41 @@ def test_closest_hit_matches_reference_vectors(binding, oracle_mod, gpu_ctx, nam
     types = prim_types(sc.flat)
     got = gpu_trace(gpu_ctx, g["world_rays"])
     compare_hits(got, g["world_hits"], types, name + " world rays", ties_ok=True)
+
+
+@pytest.mark.parametrize("name", SPECIAL_SCENES)
+def test_special_rays_match_reference(binding, oracle_mod, oracle, gpu_ctx, name):
+    """Zero and negative-zero direction components, origins on surfaces, rays through corners and vertices, directions of
+    1e18 and 1e-30 (tests/golden/geom_special_ref.npz, from the reference's flat list).  A scene that is scanned as a
+    list must give the reference's answer on ALL of them, NaN for NaN (a rect reports a hit with t = NaN for a ray in its
+    plane); through a BVH the order-free rays must (conftest.special_order_free), and on the others the device must
+    still agree with the oracle's traversal of the same tree wherever the oracle's own two orders agree."""
+    g = load_golden("geom_special_ref.npz")
+    sc, rays, exp = special_scene(binding, oracle_mod, g, name)
+    gpu_ctx.upload(sc)
+    got = gpu_trace(gpu_ctx, rays)
+    free = special_order_free(g, name)
+    scope = np.ones(len(rays), bool) if sc.flat.contents.n_bvh_nodes == 0 else free
+    assert scope.sum() > 600
+    assert np.array_equal(got["hit"][scope], exp["hit"][scope]), "hit flags"
+    h = (exp["hit"] == 1) & scope
+    assert np.array_equal(got["t"][h], exp["t"][h], equal_nan=True), "t"
+    same = got["prim"][h] == exp["prim"][h]
+    if sc.flat.contents.n_bvh_nodes == 0:
+        assert same.all()
+    else:
+        assert same.mean() > 0.5          # rays aimed at shared corners and edges: another id only at the identical t
+    for k in ("p", "n"):
+        assert np.array_equal(got[k][h][same], exp[k][h][same], equal_nan=True), k
+    # the rest (0 / 0 somewhere, or origins at 1e7) has no single answer: the order of the tests and the rounding of the
+    # culling decide.  What can be asked: the call returns, and where the oracle's list scan and its BVH traversal agree
+    # the device mostly does too (its traversal is a third order).
+    a, b2 = oracle.trace_rays(sc.flat, rays, 0.001, FLT_MAX), oracle.trace_rays(sc.flat, rays, 0.001, FLT_MAX, use_bvh=True)
+    settled = ~scope & (a["hit"] == b2["hit"]) & ((a["t"] == b2["t"]) | (a["hit"] == 0))
+    if settled.any():
+        agree = (got["hit"][settled] == a["hit"][settled]) & ((got["t"][settled] == a["t"][settled]) | (a["hit"][settled] == 0))
+        print("%s: %d rays outside the order-free set with one oracle answer, device agrees on %.3f" % (name, settled.sum(), agree.mean()))
+        assert agree.mean() > 0.98
 
 
 @pytest.mark.parametrize("name", GEOM_SCENES)
