@@ -107,7 +107,9 @@ __global__ __launch_bounds__(RT_BLOCK, wf_intersect_waves(F)) void wf_intersect_
     int gidx = 0, gi = -1, ref = RT_REF_NONE, pleaf = RT_REF_NONE, sp = 0, li = 0;
     int ovf[WF_OVF_STACK];                      /* stack entries beyond WF_LDS_STACK (scratch) */
 #define WF_PUSH(v) { const int v_ = (v); if (sp < WF_LDS_STACK) stack[sp * RT_BLOCK] = v_; else ovf[sp - WF_LDS_STACK] = v_; ++sp; }
-#define WF_POP(dst) { dst = RT_REF_NONE; if (sp > 0) { --sp; dst = sp < WF_LDS_STACK ? stack[sp * RT_BLOCK] : ovf[sp - WF_LDS_STACK]; } }
+    /* two loads in two branches: written as one conditional expression the compiler selects between the ADDRESSES and pops
+     * with a flat_load, which goes through the vector memory path as well as the LDS */
+#define WF_POP(dst) { dst = RT_REF_NONE; if (sp > 0) { --sp; if (sp < WF_LDS_STACK) dst = stack[sp * RT_BLOCK]; else dst = ovf[sp - WF_LDS_STACK]; } }
     /* the ray enters the gidx-th BVH group of the world list (GENERIC record of closest_hit: the group's own
      * wrapper chain on the world ray), or, past the last group, is finished: its hit goes to HBM */
 #define WF_NEXT_GROUP                                                                                            \
