@@ -2,7 +2,7 @@
 # (each in a run of its own) for the Cornell megakernel and for the wavefront kernels on the triangle scene.
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/${1:-r02c}
+O=gpurun_out/${1:-r02d}
 mkdir -p $O
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_default -- python3 bench.py --no-cpu-baseline --no-extras > $O/trace_default.log 2>&1
 C="python3 bench.py --no-cpu-baseline --no-extras --steps 1 --warmup 0"
