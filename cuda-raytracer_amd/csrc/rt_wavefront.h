@@ -496,10 +496,18 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_logic_kernel(DScene S, WfState W,
     if (first >= n_queue) return;                             /* whole block beyond the queue */
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
     uint32_t* __restrict__ queue = W.queue[qi];
+    /* the queue entries of all the tiles first: one round trip instead of one per tile in front of the state loads */
+    uint32_t slots_of[WF_LOGIC_TILES];
+#pragma unroll
     for (int tile = 0; tile < WF_LOGIC_TILES; ++tile) {
         const uint32_t e = first + tile * RT_BLOCK + threadIdx.x;
+        slots_of[tile] = e < n_queue ? queue[e] : 0u;
+    }
+    static_assert(WF_LOGIC_TILES == 4, "the select below is written for four tiles");
+    for (int tile = 0; tile < WF_LOGIC_TILES; ++tile) {       /* stays a loop: the body is the whole bounce */
+        const uint32_t e = first + tile * RT_BLOCK + threadIdx.x;
         const bool active = e < n_queue;
-        const uint32_t slot = active ? queue[e] : 0u;
+        const uint32_t slot = tile == 0 ? slots_of[0] : (tile == 1 ? slots_of[1] : (tile == 2 ? slots_of[2] : slots_of[3]));
         bool alive = false;
         if (first + tile * RT_BLOCK < n_queue)                /* block-uniform: skip tiles beyond the queue */
             alive = wf_logic_one<F, BG>(S, W, active, slot, Wd, Hd, s_end, k0, k1, max_depth, slots);
