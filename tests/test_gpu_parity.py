@@ -555,6 +555,57 @@ def test_wavefront_pools_do_not_change_the_image(binding, gpu_ctx, monkeypatch):
             assert torch.equal(im, images[0]) and r == rays[0]
 
 
+def test_wavefront_scheduling_switches_do_not_change_the_image(binding, gpu_ctx, monkeypatch):
+    """Which wave takes which chunk of the ray queue (XCD-affine claims, RT_WF_AFFINE), how many idle lanes a refill waits
+    for (RT_WF_REFILL), how large the persistent intersect grid is (RT_WF_IBLOCKS) and whether a call is cut into parts
+    (RT_WF_PART) are scheduling only: a slot's samples and their order stay what they are.  Same bits, same ray count;
+    a frame of 1200 x 40 so that a stream spans several chunks and every band head is used."""
+    import torch
+    W, H, spp = 1200, 40, 24
+    for name, param in (("tri_mesh", 3000), ("final", 8)):
+        sc = binding.Scene(name, W, H, param)
+        gpu_ctx.upload(sc)
+        few = str(2 * W * H)           # two streams per pixel: every slot runs twelve samples one after the other
+        groups = (({}, {"RT_WF_AFFINE": "0"}, {"RT_WF_REFILL": "7"}, {"RT_WF_IBLOCKS": "5"}, {"RT_WF_AFFINE": "1", "RT_WF_POOLS": "1", "RT_WF_IBLOCKS": "3"}),
+                  ({"RT_WF_SLOTS": few}, {"RT_WF_SLOTS": few, "RT_WF_AFFINE": "0"}, {"RT_WF_SLOTS": few, "RT_WF_REFILL": "64", "RT_WF_POOLS": "2"}))
+        firsts = []
+        for group in groups:
+            images, rays = [], []
+            for env in group:
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                ctx = binding.Context(0) if "RT_WF_SLOTS" in env else gpu_ctx      # the slot target is read when a context is made
+                try:
+                    if ctx is not gpu_ctx:
+                        ctx.upload(sc)
+                    ctx.reset_counters()
+                    images.append(render_gpu(ctx, binding, sc, W, H, 2, 2 + spp, 9, integrator="wavefront"))
+                    rays.append(ctx.counters().rays)
+                finally:
+                    if ctx is not gpu_ctx:
+                        ctx.close()
+                    for k in env:
+                        monkeypatch.delenv(k)
+            assert float(images[0].sum()) > 0
+            for env_i, (im, r) in enumerate(zip(images[1:], rays[1:])):
+                assert torch.equal(im, images[0]) and r == rays[0], (name, env_i)
+            firsts.append((images[0], rays[0]))
+        # the two groups sum a pixel's samples in another grouping: the same paths, sums equal up to rounding
+        assert firsts[0][1] == firsts[1][1] and torch.allclose(firsts[0][0], firsts[1][0], rtol=2e-5, atol=1e-5)
+        # ... and a call cut into parts (RT_WF_PART) is the sum of its parts
+        monkeypatch.setenv("RT_WF_SLOTS", few)
+        monkeypatch.setenv("RT_WF_PART", "8")
+        ctx = binding.Context(0)
+        try:
+            ctx.upload(sc)
+            parts = render_gpu(ctx, binding, sc, W, H, 2, 2 + spp, 9, integrator="wavefront")
+        finally:
+            ctx.close()
+            monkeypatch.delenv("RT_WF_SLOTS")
+            monkeypatch.delenv("RT_WF_PART")
+        assert torch.allclose(parts, firsts[1][0], rtol=2e-5, atol=1e-5)
+
+
 def test_wavefront_failure_leaves_the_context_usable(binding, gpu_ctx, monkeypatch):
     """the wavefront loop's error exits (a queue that does not drain, a failing HIP call) wait for every pool's stream
     before returning: forced here with RT_WF_DEBUG_MAX_ITERS=0, after which the same context renders as if nothing
