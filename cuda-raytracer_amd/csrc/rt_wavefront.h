@@ -483,8 +483,15 @@ __device__ __forceinline__ bool wf_logic_one(const DScene& S, const WfState& W, 
 #define WF_LOGIC_TILES 4
 #endif
 #define WF_SPAN (RT_BLOCK * WF_LOGIC_TILES)
+/* waves per SIMD the logic kernel is compiled for.  The all-feature variant needs 117 VGPRs; at 5 waves it fits 96 with
+ * 8 bytes spilled and at 6 waves 80 with 48 bytes, and both are SLOWER (final scene 3.89 -> 3.75 / 3.68 Grays/s, Cornell +
+ * sphere cluster 4.76 -> 4.61; the triangle variant has 70 and does not care): the kernel waits for its state rows,
+ * but more of its waves only take wave slots and memory requests away from the intersect kernels of the other pools */
+#ifndef WF_LOGIC_WAVES
+#define WF_LOGIC_WAVES 4
+#endif
 template <uint32_t F, int BG>
-__global__ __launch_bounds__(RT_BLOCK) void wf_logic_kernel(DScene S, WfState W, int qi, int Wd, int Hd, uint32_t s_end,
+__global__ __launch_bounds__(RT_BLOCK, WF_LOGIC_WAVES) void wf_logic_kernel(DScene S, WfState W, int qi, int Wd, int Hd, uint32_t s_end,
                                                             uint32_t k0, uint32_t k1, int max_depth)
 {
     __shared__ int slot_mem[RT_BLOCK];
