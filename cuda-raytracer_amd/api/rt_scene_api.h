@@ -332,15 +332,26 @@ public:
 };
 
 /* ------------------------------------------------------------------ camera -- */
-/* Same constructor signature as Camera.cuh:23.  Like every class here it only records: the nine arguments are kept
- * as given and rt::lower() derives the 96-byte camera block of include/rt_scene.h from them (csrc/lower.cpp,
- * camera_block, which cites the operation order it has to keep). */
+/* Same constructor signature and the same public data members as the reference's Camera (Camera.cuh:23, :47-49:
+ * lowerLeftCorner, horizontal, vertical, origin, u, v, w, lensRadius, time0, time1), so a program that reads
+ * (*dCamera)->origin or ->lensRadius compiles and sees the reference's values.  The members are filled by ONE routine,
+ * rt::derive_camera (csrc/lower.cpp, compiled without FMA contraction, which cites the operation order it has to keep);
+ * rt::lower() copies them into the 96-byte camera block of include/rt_scene.h.  The nine arguments are kept as given
+ * beside them. */
+class Camera;
+namespace rt { void derive_camera(Camera& cam); }
 class Camera : public rt::Node {
 public:
     Camera(Vector3 lookfrom, Vector3 lookat, Vector3 vup, float vfov, float aspect, float aperture,
            float focusDist, float t0, float t1)
-        : eye(lookfrom), target(lookat), upHint(vup), vfovDegrees(vfov), aspectRatio(aspect), apertureDiameter(aperture),
-          focusDistance(focusDist), shutterOpen(t0), shutterClose(t1) {}
+        : lensRadius(0.f), time0(t0), time1(t1),
+          eye(lookfrom), target(lookat), upHint(vup), vfovDegrees(vfov), aspectRatio(aspect), apertureDiameter(aperture),
+          focusDistance(focusDist), shutterOpen(t0), shutterClose(t1)
+    { rt::derive_camera(*this); }
+    Vector3 lowerLeftCorner, horizontal, vertical, origin;
+    Vector3 u, v, w;
+    float lensRadius, time0, time1;
+    /* the constructor's arguments as given */
     Vector3 eye, target, upHint;
     float vfovDegrees, aspectRatio, apertureDiameter, focusDistance, shutterOpen, shutterClose;
 };

@@ -66,7 +66,8 @@ class RtHitRecord(C.Structure):
 
 class RtCounters(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("render_ms", C.c_double),
-                ("last_render_ms", C.c_double), ("render_launches", C.c_uint32), ("last_integrator", C.c_uint32)]
+                ("last_render_ms", C.c_double), ("render_launches", C.c_uint32), ("last_integrator", C.c_uint32),
+                ("wf_pools", C.c_uint32), ("wf_streams_found", C.c_uint32)]
 
 
 # numpy dtype with the layout of rt_scatter_record / rto_scatter_out (60 bytes)
@@ -80,7 +81,7 @@ EXPORTS = [
     "rt_last_error", "rt_scene_create_builtin", "rt_scene_from_flat", "rt_scene_flat",
     "rt_scene_default_background", "rt_scene_destroy", "rt_ctx_create", "rt_ctx_destroy",
     "rt_scene_upload", "rt_trace_rays", "rt_trace_primary", "rt_shade_rays", "rt_texture_values", "rt_render_accumulate", "rt_render_accumulate_window", "rt_render_accumulate_noalloc", "rt_resolve",
-    "rt_ctx_set_integrator", "rt_reduce_accum", "rt_reduce_scatter_rows", "rt_synchronize", "rt_get_counters", "rt_reset_counters", "rt_quantise_rgb8", "rt_write_ppm", "rt_write_png", "rt_read_ppm", "rt_free_pixels", "rt_flat_features", "rt_flat_program", "rt_flat_program_split", "rt_flat_bvh_stats",
+    "rt_ctx_set_integrator", "rt_reduce_accum", "rt_reduce_scatter_rows", "rt_synchronize", "rt_get_counters", "rt_reset_counters", "rt_quantise_rgb8", "rt_write_ppm", "rt_write_png", "rt_read_ppm", "rt_free_pixels", "rt_flat_features", "rt_flat_program", "rt_flat_program_split", "rt_flat_bvh_stats", "rt_flat_bvh4_single_refs",
 ]
 
 
@@ -130,7 +131,18 @@ def load_library(path=LIB_PATH):
     lib.rt_flat_program.argtypes = [C.POINTER(RtFlatScene), vp, i32]
     lib.rt_flat_program_split.argtypes = [C.POINTER(RtFlatScene), vp, i32, vp, i32, C.POINTER(C.c_int)]
     lib.rt_flat_bvh_stats.argtypes = [C.POINTER(RtFlatScene)] + [C.POINTER(C.c_int)] * 4
+    lib.rt_flat_bvh4_single_refs.argtypes = [C.POINTER(RtFlatScene)]
     return lib
+
+
+def load_reduce_test_library():
+    """TEST build of csrc/rt_reduce.cpp (-DRT_TEST_HOOKS): the exchange logic with rt_debug_reduce_with_fake; tests only"""
+    path = os.path.join(_HERE, "librt_reduce_test.so")
+    if not os.path.exists(path):
+        raise RtError("%s is missing: build it with `make -C cuda-raytracer_amd`" % path)
+    t = C.CDLL(path)
+    t.rt_last_error.restype = C.c_char_p
+    return t
 
 
 _lib = None

@@ -489,12 +489,13 @@ struct Lowerer {
     }
 };
 
-/* The camera block from the recorded constructor arguments.  The values must carry the roundings of the reference's
- * constructor (Camera.cuh:23-39), so the order of the fp32 operations is the reference's: theta = (vfov * pi) / 180 with
- * pi narrowed to float first; half height = tan(theta / 2) in float; basis w = unit(from - at), u = unit(up x w),
- * v = w x u; corner = ((from - (hw * u) * fd) - (hh * v) * fd) - w * fd; spans = ((2 * hw) * u) * fd and ((2 * hh) * v) * fd;
- * lens radius = aperture / 2.  Built with -ffp-contract=off like everything else here. */
-static void camera_block(const Camera& k, rt_camera& c)
+/* The reference-named members of a Camera from its recorded constructor arguments (called by the constructor,
+ * api/rt_scene_api.h).  The values must carry the roundings of the reference's constructor (Camera.cuh:23-39), so the
+ * order of the fp32 operations is the reference's: theta = (vfov * pi) / 180 with pi narrowed to float first; half height =
+ * tan(theta / 2) in float; basis w = unit(from - at), u = unit(up x w), v = w x u; corner = ((from - (hw * u) * fd) -
+ * (hh * v) * fd) - w * fd; spans = ((2 * hw) * u) * fd and ((2 * hh) * v) * fd; lens radius = aperture / 2.  Built with
+ * -ffp-contract=off like everything else here. */
+void derive_camera(Camera& k)
 {
     const float theta = k.vfovDegrees * ((float)M_PI) / 180.f;
     const float hh = std::tan(theta / 2);
@@ -507,17 +508,33 @@ static void camera_block(const Camera& k, rt_camera& c)
     for (int a = 0; a < 3; ++a) {
         const float along_u = hw * right.e[a] * fd;
         const float along_v = hh * above.e[a] * fd;
-        c.origin[a] = k.eye.e[a];
-        c.lower_left[a] = k.eye.e[a] - along_u - along_v - back.e[a] * fd;
-        c.horizontal[a] = two_hw * right.e[a] * fd;
-        c.vertical[a] = two_hh * above.e[a] * fd;
-        c.u[a] = right.e[a];
-        c.v[a] = above.e[a];
-        c.w[a] = back.e[a];
+        k.origin.e[a] = k.eye.e[a];
+        k.lowerLeftCorner.e[a] = k.eye.e[a] - along_u - along_v - back.e[a] * fd;
+        k.horizontal.e[a] = two_hw * right.e[a] * fd;
+        k.vertical.e[a] = two_hh * above.e[a] * fd;
     }
-    c.lens_radius = k.apertureDiameter / 2.f;
-    c.time0 = k.shutterOpen;
-    c.time1 = k.shutterClose;
+    k.u = right; k.v = above; k.w = back;
+    k.lensRadius = k.apertureDiameter / 2.f;
+    k.time0 = k.shutterOpen;
+    k.time1 = k.shutterClose;
+}
+
+/* the 96-byte camera block of include/rt_scene.h: the members as derive_camera left them (a scene function may have
+ * edited them afterwards, as it could the reference's) */
+static void camera_block(const Camera& k, rt_camera& c)
+{
+    for (int a = 0; a < 3; ++a) {
+        c.origin[a] = k.origin.e[a];
+        c.lower_left[a] = k.lowerLeftCorner.e[a];
+        c.horizontal[a] = k.horizontal.e[a];
+        c.vertical[a] = k.vertical.e[a];
+        c.u[a] = k.u.e[a];
+        c.v[a] = k.v.e[a];
+        c.w[a] = k.w.e[a];
+    }
+    c.lens_radius = k.lensRadius;
+    c.time0 = k.time0;
+    c.time1 = k.time1;
 }
 
 bool lower(Hitable* world, const Camera* cam, const LowerOptions& opt, FlatScene& out, std::string& err)
@@ -525,8 +542,8 @@ bool lower(Hitable* world, const Camera* cam, const LowerOptions& opt, FlatScene
     out = FlatScene();
     Lowerer L(out, opt, err);
     if (!world || !cam) { err = "null world or camera"; return false; }
-    L.shutter0 = cam->shutterOpen;
-    L.shutter1 = cam->shutterClose;
+    L.shutter0 = cam->time0;
+    L.shutter1 = cam->time1;
     /* the root is always a GROUP; a bare object becomes a one-element world */
     out.objects.resize(1);
     if (world->kind() == Hitable::LIST || world->kind() == Hitable::BVH) {

@@ -246,11 +246,27 @@ void rt_pack_bvh4(const rt_flat_scene* s, std::vector<DObj>& objs, std::vector<D
             /* Slots still free (the bottom of the tree: two leaf children and nothing left to open): a leaf of several
              * items is opened into one child per item, each behind its OWN box, so that a primitive is only fetched and
              * tested when the ray meets that primitive's box, not its neighbour's.  The node count does not change. */
+            /* An opened item sits behind rt_object::bmin/bmax, which nothing else on the device reads: a caller's table
+             * (rt_scene_from_flat) may have the node boxes right and the object bounds unset or stale.  A leaf is only
+             * opened when every item's padded box is finite, ordered and inside the leaf's own box (what a builder that
+             * made the node from the items guarantees, up to rounding); otherwise it stays one child behind the node's box. */
+            auto openable = [&](const rt_bvh_node& leaf) {
+                for (uint32_t q = 0; q < leaf.count; ++q) {
+                    const rt_object& o = s->objects[s->bvh_items[leaf.left_first + q]];
+                    for (int a = 0; a < 3; ++a) {
+                        if (!(std::isfinite(o.bmin[a]) && std::isfinite(o.bmax[a]) && o.bmin[a] <= o.bmax[a])) return false;
+                        const float m = std::max(std::fabs(o.bmin[a]), std::fabs(o.bmax[a])), slack = 4e-5f * m + 4e-4f;
+                        if (o.bmin[a] < leaf.bmin[a] - slack || o.bmax[a] > leaf.bmax[a] + slack) return false;
+                    }
+                }
+                return true;
+            };
             while (nc < 4) {
                 int pick = -1;
                 uint32_t most = 1;
                 for (int k = 0; k < nc; ++k)
-                    if (cands[k].item < 0 && s->bvh_nodes[cands[k].node].count > most && (int)s->bvh_nodes[cands[k].node].count <= 5 - nc) {
+                    if (cands[k].item < 0 && s->bvh_nodes[cands[k].node].count > most && (int)s->bvh_nodes[cands[k].node].count <= 5 - nc &&
+                        openable(s->bvh_nodes[cands[k].node])) {
                         most = s->bvh_nodes[cands[k].node].count; pick = k;
                     }
                 if (pick < 0) break;
@@ -435,6 +451,20 @@ extern "C" int rt_flat_program_split(const rt_flat_scene* flat, uint32_t* out_wo
     if (g) std::memcpy(out_groups, groups.data(), g * sizeof(int32_t));
     *n_groups = (int)groups.size();
     return (int)plain.size();
+}
+
+/* single-item leaf references of the 4-wide trees (opened leaves and leaves the builder made of one item) */
+extern "C" int rt_flat_bvh4_single_refs(const rt_flat_scene* flat)
+{
+    std::string why;
+    if (!flat || !rt_validate_scene(flat, why, nullptr)) { rt_set_error("rt_flat_bvh4_single_refs: invalid scene: " + why); return RT_ERR_ARG; }
+    std::vector<DObj> objs((size_t)flat->n_objects);
+    rt_pack_objects(flat, objs.data());
+    std::vector<DNode4> n4;
+    rt_pack_bvh4(flat, objs, n4, nullptr);
+    int n = 0;
+    for (const DNode4& d : n4) for (int k = 0; k < 4; ++k) if (d.ref[k] < 0 && d.ref[k] != RT_REF_NONE && ((uint32_t)(~d.ref[k]) & 15u) == 0u) ++n;
+    return n;
 }
 
 extern "C" int rt_flat_bvh_stats(const rt_flat_scene* flat, int* nodes2, int* depth2, int* nodes4, int* depth4)

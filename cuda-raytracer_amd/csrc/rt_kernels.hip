@@ -13,8 +13,6 @@
  * by its own queue traffic there.
  */
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
-#include <dlfcn.h>
 #include <chrono>
 #include <mutex>
 #include <cstdio>
@@ -26,6 +24,7 @@
 #include "rt_device.h"
 #include "rt_host.h"
 #include "rt_wavefront.h"
+#include "rt_reduce.h"
 
 /* feature sets the render kernel is compiled for (rt_host.h RT_F_*); a scene runs on the first one
  * that covers it.  Leaving out what a scene cannot contain keeps the kernel's register and
@@ -122,7 +121,7 @@ __global__ __launch_bounds__(RT_BLOCK) void trace_rays_kernel(DScene S, int n, c
  * device code as the integrators: the wave-wide unit-ball draw, then scatter<F>. */
 template <uint32_t F>
 __global__ __launch_bounds__(RT_BLOCK) void shade_rays_kernel(DScene S, int n, const float* __restrict__ rays, const float* __restrict__ recs,
-                                                               const int32_t* __restrict__ materials, const uint32_t* __restrict__ psb,
+                                                               const int32_t* __restrict__ materials, int n_materials, const uint32_t* __restrict__ psb,
                                                                uint32_t k0, uint32_t k1, rt_scatter_record* __restrict__ out)
 {
     __shared__ int slot_mem[RT_BLOCK];
@@ -137,6 +136,7 @@ __global__ __launch_bounds__(RT_BLOCK) void shade_rays_kernel(DScene S, int n, c
     rng_start(g, k0, k1, 0u, 0u);
     uint32_t bounce = 0;
     int mtype = RT_MAT_LIGHT;
+    bool in_range = false;
     if (active) {
         const float* q = rays + 7 * (size_t)i;
         const float* h = recs + 9 * (size_t)i;
@@ -146,11 +146,20 @@ __global__ __launch_bounds__(RT_BLOCK) void shade_rays_kernel(DScene S, int n, c
         rec.material = materials[i];
         rng_start(g, k0, k1, psb[3 * (size_t)i], psb[3 * (size_t)i + 1]);
         bounce = psb[3 * (size_t)i + 2];
-        mtype = S.mats[rec.material].type;
+        in_range = rec.material >= 0 && rec.material < n_materials;      /* the indices are the caller's: never followed unchecked */
+        if (in_range) mtype = S.mats[rec.material].type;
     }
-    const bool need_ball = active && mtype != RT_MAT_LIGHT && mtype != RT_MAT_GLASS;
+    /* a lane with a bad index stays in the wave-wide draw (as a lane that needs nothing) and reports ok = -1 */
+    const bool need_ball = active && in_range && mtype != RT_MAT_LIGHT && mtype != RT_MAT_GLASS;
     const V3 ball = random_in_unit_sphere_wave(g, bounce, need_ball, slots);
     if (!active) return;
+    if (!in_range) {
+        rt_scatter_record bad;
+        memset(&bad, 0, sizeof bad);
+        bad.ok = -1;
+        out[i] = bad;
+        return;
+    }
     V3 attenuation, emitted;
     DRay scattered;
     const bool ok = scatter<F>(S, r, rec, g, bounce, ball, attenuation, scattered, emitted);
@@ -410,6 +419,7 @@ struct rt_ctx {
     uint32_t features = 0;    /* RT_F_* of the uploaded scene */
     int integrator = RT_INTEGRATOR_AUTO;
     int last_integrator = 0;          /* form the latest render call ran in (rt_counters) */
+    int last_wf_pools = 0;            /* pools the latest wavefront call ran as (rt_counters) */
     /* wavefront path state (rt_wavefront.h), allocated on first use and kept */
     WfState wf = {};
     void* wf_mem = nullptr;
@@ -425,6 +435,7 @@ struct rt_ctx {
     void* d_objs = nullptr;  void* d_ops = nullptr;   void* d_mats = nullptr; void* d_texs = nullptr;
     void* d_image = nullptr; void* d_nodes = nullptr; void* d_leafs = nullptr; void* d_prog = nullptr; void* d_nodes4 = nullptr;
     float* d_partial = nullptr; size_t partial_floats = 0;    /* per-group frames of the megakernel's sample groups */
+    float* noalloc_scratch = nullptr;  /* this device's copy of rt_noalloc_scratch, looked up at rt_ctx_create */
     void* d_prog_wf = nullptr; void* d_wf_groups = nullptr;   /* the world list in the wavefront integrator's form */
     int n_wf_groups = 0, n_wf_plain = 0;
     unsigned long long* d_counters = nullptr;
@@ -468,9 +479,11 @@ extern "C" int rt_ctx_create(int device, void* stream, rt_ctx** out)
     HIPCHK(hipGetDeviceCount(&n));
     if (device < 0 || device >= n) { rt_set_error("rt_ctx_create: no such device"); return RT_ERR_ARG; }
     HIPCHK(hipSetDevice(device));
-    { int src = noalloc_scratch_for(device, nullptr); if (src) return src; }
+    float* scratch = nullptr;
+    { int src = noalloc_scratch_for(device, &scratch); if (src) return src; }
     rt_ctx* c = new rt_ctx();
     c->device = device;
+    c->noalloc_scratch = scratch;
     if (const char* e = std::getenv("RT_WF_SLOTS")) { const long long v = std::atoll(e); if (v > 0) c->wf_slots_target = (size_t)v; }
     if (stream) c->stream = (hipStream_t)stream;
     else {
@@ -620,9 +633,9 @@ extern "C" int rt_shade_rays(rt_ctx* c, int n, const float* rays, const float* r
     if (n < 0 || (n && (!rays || !recs || !materials || !psb || !out))) { rt_set_error("rt_shade_rays: bad arguments"); return RT_ERR_ARG; }
     if (n == 0) return RT_OK;
     HIPCHK(hipSetDevice(c->device));
-    /* material indices come from the caller's device memory: they are range-checked by the scene's material count on
-     * the host side of the tests only; a parity hook, not a render path */
-    shade_rays_kernel<RT_V_NOISE><<<dim3((unsigned)((n + RT_BLOCK - 1) / RT_BLOCK)), RT_BLOCK, 0, c->stream>>>(c->ds, n, rays, recs, materials, psb,
+    /* material indices come from the caller's device memory: the kernel checks them against the scene's material count
+     * and reports ok = -1 for one out of range */
+    shade_rays_kernel<RT_V_NOISE><<<dim3((unsigned)((n + RT_BLOCK - 1) / RT_BLOCK)), RT_BLOCK, 0, c->stream>>>(c->ds, n, rays, recs, materials, c->n_materials, psb,
                                                                                                           (uint32_t)seed, (uint32_t)(seed >> 32), out);
     HIPCHK(hipGetLastError());
     return RT_OK;
@@ -829,6 +842,8 @@ static int wf_run_part(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t 
         if (n_pools > c->wf_n_streams) n_pools = c->wf_n_streams;
         if (n_pools < 2) n_pools = 1;          /* no two streams that overlap: one pool on the context's stream */
     }
+    c->last_wf_pools = n_pools;
+    if (std::getenv("RT_WF_DEBUG")) std::fprintf(stderr, "wf_run_part: %d pool(s), %d overlapping stream(s) found\n", n_pools, c->wf_n_streams);
     struct Pool { WfState W; hipStream_t st; uint32_t known; int cur; bool pending; unsigned long long iters, max_iters; uint32_t* host; };
     Pool pools[WF_MAX_POOLS];
     W.stream0 = 0;
@@ -1013,11 +1028,20 @@ extern "C" int rt_render_accumulate_window(rt_ctx* c, int w, int h, int x0, int 
     const int4 win = make_int4(x0, y0, x1 - x0, y1 - y0);
     if (s1 == s0) return RT_OK;
     HIPCHK(hipSetDevice(c->device));
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0));
-    HIPCHK(hipEventCreate(&e1));
+    /* the event pair that times the call: from here to note_render (which takes it over) every failure leaves through
+     * `fail`, which destroys both */
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto fail = [&](hipError_t e, const char* what) {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        rt_set_error(std::string("HIP error ") + hipGetErrorString(e) + " at " + what);
+        return RT_ERR_HIP;
+    };
+#define EVCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(e_, #expr); } while (0)
+    EVCHK(hipEventCreate(&e0));
+    EVCHK(hipEventCreate(&e1));
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    HIPCHK(hipEventRecord(e0, c->stream));
+    EVCHK(hipEventRecord(e0, c->stream));
     /* auto: the wavefront form pays off as soon as a BVH is traversed.  Measured at 1920x1080 (tools/compare_integrators.py),
      * wavefront / megakernel: 1M triangles 1.97, 200 k 1.61, 20 k 1.21; final scene (11 k or 1.4 k items) 2.29-2.41; Cornell +
      * 1000-sphere cluster 1.51; 488 spheres in a world BVH 1.17; 16 boxes 0.48; no BVH at all (Cornell) 0.31. */
@@ -1033,7 +1057,7 @@ extern "C" int rt_render_accumulate_window(rt_ctx* c, int w, int h, int x0, int 
                   : (c->features & ~RT_V_NOTRI) == 0 ? wf_run<RT_V_NOTRI>(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum)
                   : (c->features & ~RT_F_ALL) == 0   ? wf_run<RT_F_ALL>(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum)
                                                      : wf_run<RT_V_NOISE>(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum);
-        HIPCHK(hipEventRecord(e1, c->stream));
+        EVCHK(hipEventRecord(e1, c->stream));
         int nrc = note_render(c, e0, e1);
         return wrc ? wrc : nrc;
     }
@@ -1043,7 +1067,7 @@ extern "C" int rt_render_accumulate_window(rt_ctx* c, int w, int h, int x0, int 
     if (groups > 1) {
         const size_t need = (size_t)groups * (size_t)w * (size_t)h * 3;
         if (need > c->partial_floats) {
-            HIPCHK(hipStreamSynchronize(c->stream));
+            EVCHK(hipStreamSynchronize(c->stream));
             if (c->d_partial) { (void)hipFree(c->d_partial); c->d_partial = nullptr; c->partial_floats = 0; }
             if (hipMalloc((void**)&c->d_partial, need * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); groups = 1; }
             else c->partial_floats = need;
@@ -1051,7 +1075,8 @@ extern "C" int rt_render_accumulate_window(rt_ctx* c, int w, int h, int x0, int 
         partial = groups > 1 ? c->d_partial : nullptr;
     }
     hipError_t le = mega_launch(c, w, h, win, s0, s1, k0, k1, max_depth, background, accum, groups, per_group, partial);
-    HIPCHK(hipEventRecord(e1, c->stream));
+    EVCHK(hipEventRecord(e1, c->stream));
+#undef EVCHK
     int nrc = note_render(c, e0, e1);
     if (le != hipSuccess) { rt_set_error(std::string("render launch failed: ") + hipGetErrorString(le)); return RT_ERR_HIP; }
     return nrc;
@@ -1072,6 +1097,11 @@ extern "C" int rt_render_accumulate_noalloc(rt_ctx* c, int w, int h, uint32_t s0
     if (s1 == s0) return RT_OK;
     uint32_t groups, per_group;
     mega_runs(s1 - s0, groups, per_group);
+    if (groups > 16u) {              /* RT_MEGA_GROUPS (a measurement switch) may ask for more runs: the documented limit is 16 here */
+        groups = 16u;
+        per_group = (s1 - s0 + groups - 1) / groups;
+        groups = (s1 - s0 + per_group - 1) / per_group;
+    }
     if (groups > 1 && (unsigned long long)groups * (unsigned long long)w * (unsigned long long)h * 3ull > (unsigned long long)RT_NOALLOC_FLOATS) {
         rt_set_error("rt_render_accumulate_noalloc: " + std::to_string(groups) + " runs of a " + std::to_string(w) + "x" + std::to_string(h) +
                      " frame need more than the " + std::to_string((unsigned long long)RT_NOALLOC_FLOATS * 4ull >> 20) +
@@ -1079,8 +1109,8 @@ extern "C" int rt_render_accumulate_noalloc(rt_ctx* c, int w, int h, uint32_t s0
         return RT_ERR_ARG;
     }
     HIPCHK(hipSetDevice(c->device));
-    float* scratch = nullptr;
-    if ((rc = noalloc_scratch_for(c->device, &scratch))) return rc;      /* a table lookup after rt_ctx_create */
+    float* scratch = c->noalloc_scratch;      /* resolved at rt_ctx_create: no lock, no lookup here */
+    if (!scratch) { rt_set_error("rt_render_accumulate_noalloc: the context has no scratch address"); return RT_ERR_HIP; }
     c->last_integrator = RT_INTEGRATOR_MEGAKERNEL;
     /* every (run, pixel) cell the combine step reads is written by the render kernel of the same call first (a pixel hands
      * in each of its runs, black ones included), so what an earlier call left in the array is never read: nothing to clear */
@@ -1101,114 +1131,9 @@ extern "C" int rt_resolve(rt_ctx* c, const float* accum, int w, int h, uint32_t 
     return RT_OK;
 }
 
-/* ---- RCCL reduce of per-GPU accumulation buffers ------------------------------------------------------
- * librccl.so is opened on first use (a single-GPU process never pays for it); types come from <rccl/rccl.h>.
- * The exchange logic (argument checks, communicator cache, the grouped reduces) works on a table of function
- * pointers and on plain device / stream / buffer lists, so that it can be driven without GPUs: the real table is
- * filled from librccl + hipSetDevice, tests/test_reduce_cpu.py injects a recording one through
- * rt_debug_reduce_with_fake (no machine here or in the one-GPU box has two devices to run the real one on). */
-namespace {
-struct RcclOps {
-    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*GroupStart)() = nullptr;
-    ncclResult_t (*GroupEnd)() = nullptr;
-    ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
-    const char* (*GetErrorString)(ncclResult_t) = nullptr;
-    hipError_t (*SetDevice)(int) = nullptr;
-};
-struct RcclState {
-    void* handle = nullptr;
-    RcclOps ops;
-    std::vector<int> devices;          /* the device list the cached communicators were made for */
-    std::vector<ncclComm_t> comms;
-};
-RcclState g_rccl;
-std::mutex g_rccl_mutex;
-
-int rccl_load()
-{
-    if (g_rccl.handle) return RT_OK;
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-    if (!h) { rt_set_error(std::string("rt_reduce_accum: cannot load librccl: ") + dlerror()); return RT_ERR_RCCL; }
-    bool ok = true;
-    auto sym = [&](const char* name) { void* p = dlsym(h, name); if (!p) ok = false; return p; };
-    RcclOps& o = g_rccl.ops;
-    o.CommInitAll = (decltype(o.CommInitAll))sym("ncclCommInitAll");
-    o.CommDestroy = (decltype(o.CommDestroy))sym("ncclCommDestroy");
-    o.GroupStart = (decltype(o.GroupStart))sym("ncclGroupStart");
-    o.GroupEnd = (decltype(o.GroupEnd))sym("ncclGroupEnd");
-    o.Reduce = (decltype(o.Reduce))sym("ncclReduce");
-    o.GetErrorString = (decltype(o.GetErrorString))sym("ncclGetErrorString");
-    o.SetDevice = &hipSetDevice;
-    if (!ok) { dlclose(h); rt_set_error("rt_reduce_accum: librccl lacks an expected symbol"); return RT_ERR_RCCL; }
-    g_rccl.handle = h;
-    return RT_OK;
-}
-#define RCCLCHK(st, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { \
-    rt_set_error(std::string(#call) + ": " + (st).ops.GetErrorString(r_)); return RT_ERR_RCCL; } } while (0)
-
-/* checks the lists and makes sure `st` holds communicators for exactly this device list (made on first use, kept
- * for the next call, replaced when the list changes) */
-int rccl_comms(RcclState& st, const char* who, const int* devices, float* const* accum, int n)
-{
-    for (int i = 0; i < n; ++i) {
-        if (!accum[i]) { rt_set_error(std::string(who) + ": null context or buffer"); return RT_ERR_ARG; }
-        for (int j = 0; j < i; ++j)
-            if (devices[j] == devices[i]) { rt_set_error(std::string(who) + ": two contexts on one device"); return RT_ERR_ARG; }
-    }
-    const std::vector<int> want(devices, devices + n);
-    if (st.devices != want) {
-        for (ncclComm_t c : st.comms) if (c) (void)st.ops.CommDestroy(c);
-        st.comms.assign(n, nullptr);
-        st.devices.clear();
-        RCCLCHK(st, st.ops.CommInitAll(st.comms.data(), n, want.data()));
-        st.devices = want;
-    }
-    return RT_OK;
-}
-
-/* rank i = position i in the lists; in place: the root's buffer receives the sum */
-int reduce_accum_impl(RcclState& st, const int* devices, const hipStream_t* streams, float* const* accum, int n, uint64_t count, int root)
-{
-    if (n < 1 || root < 0 || root >= n || count == 0 || !devices || !streams || !accum) { rt_set_error("rt_reduce_accum: bad arguments"); return RT_ERR_ARG; }
-    int rc = rccl_comms(st, "rt_reduce_accum", devices, accum, n);
-    if (rc) return rc;
-    RCCLCHK(st, st.ops.GroupStart());
-    for (int i = 0; i < n; ++i) {
-        if (st.ops.SetDevice(devices[i]) != hipSuccess) { (void)st.ops.GroupEnd(); rt_set_error("rt_reduce_accum: hipSetDevice failed"); return RT_ERR_HIP; }
-        ncclResult_t r = st.ops.Reduce(accum[i], accum[i], (size_t)count, ncclFloat, ncclSum, root, st.comms[i], streams[i]);
-        if (r != ncclSuccess) { (void)st.ops.GroupEnd(); rt_set_error(std::string("ncclReduce: ") + st.ops.GetErrorString(r)); return RT_ERR_RCCL; }
-    }
-    RCCLCHK(st, st.ops.GroupEnd());
-    return RT_OK;
-}
-
-/* one reduce per band, rooted at the band's owner, all in one group: every GPU receives 1/n of the frame
- * instead of GPU 0 receiving all of it (bands may differ in height, which ncclReduceScatter cannot express) */
-int reduce_scatter_impl(RcclState& st, const int* devices, const hipStream_t* streams, float* const* accum, int n, int w, int h, int* rows)
-{
-    if (n < 1 || !frame_ok(w, h) || !rows || !devices || !streams || !accum) { rt_set_error("rt_reduce_scatter_rows: bad arguments"); return RT_ERR_ARG; }
-    int rc = rccl_comms(st, "rt_reduce_scatter_rows", devices, accum, n);
-    if (rc) return rc;
-    for (int i = 0; i <= n; ++i) rows[i] = (int)((long long)h * i / n);
-    RCCLCHK(st, st.ops.GroupStart());
-    for (int band = 0; band < n; ++band) {
-        const size_t off = (size_t)rows[band] * w * 3, cnt = (size_t)(rows[band + 1] - rows[band]) * w * 3;
-        if (cnt == 0) continue;
-        for (int i = 0; i < n; ++i) {
-            if (st.ops.SetDevice(devices[i]) != hipSuccess) { (void)st.ops.GroupEnd(); rt_set_error("rt_reduce_scatter_rows: hipSetDevice failed"); return RT_ERR_HIP; }
-            ncclResult_t r = st.ops.Reduce(accum[i] + off, accum[i] + off, cnt, ncclFloat, ncclSum, band, st.comms[i], streams[i]);
-            if (r != ncclSuccess) { (void)st.ops.GroupEnd(); rt_set_error(std::string("ncclReduce: ") + st.ops.GetErrorString(r)); return RT_ERR_RCCL; }
-        }
-    }
-    RCCLCHK(st, st.ops.GroupEnd());
-    return RT_OK;
-}
-
-/* the contexts' devices and streams as plain lists */
-int ctx_lists(const char* who, rt_ctx* const* ctxs, float* const* accum, int n, std::vector<int>& devices, std::vector<hipStream_t>& streams)
+/* ---- RCCL reduce of per-GPU accumulation buffers: csrc/rt_reduce.cpp holds the exchange logic (plain device / stream /
+ * buffer lists, no rt_ctx); here the contexts are turned into those lists. */
+static int ctx_lists(const char* who, rt_ctx* const* ctxs, float* const* accum, int n, std::vector<int>& devices, std::vector<hipStream_t>& streams)
 {
     if (!ctxs || !accum || n < 1) { rt_set_error(std::string(who) + ": bad arguments"); return RT_ERR_ARG; }
     devices.resize(n);
@@ -1220,7 +1145,6 @@ int ctx_lists(const char* who, rt_ctx* const* ctxs, float* const* accum, int n, 
     }
     return RT_OK;
 }
-}  // namespace
 
 extern "C" int rt_reduce_accum(rt_ctx* const* ctxs, float* const* accum, int n, uint64_t count, int root)
 {
@@ -1229,9 +1153,7 @@ extern "C" int rt_reduce_accum(rt_ctx* const* ctxs, float* const* accum, int n, 
     std::vector<hipStream_t> streams;
     int rc = ctx_lists("rt_reduce_accum", ctxs, accum, n, devices, streams);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(g_rccl_mutex);
-    if ((rc = rccl_load())) return rc;
-    return reduce_accum_impl(g_rccl, devices.data(), streams.data(), accum, n, count, root);
+    return rt_reduce_accum_lists(devices.data(), streams.data(), accum, n, count, root);
 }
 
 extern "C" int rt_reduce_scatter_rows(rt_ctx* const* ctxs, float* const* accum, int n, int w, int h, int* rows)
@@ -1241,68 +1163,7 @@ extern "C" int rt_reduce_scatter_rows(rt_ctx* const* ctxs, float* const* accum, 
     std::vector<hipStream_t> streams;
     int rc = ctx_lists("rt_reduce_scatter_rows", ctxs, accum, n, devices, streams);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(g_rccl_mutex);
-    if ((rc = rccl_load())) return rc;
-    return reduce_scatter_impl(g_rccl, devices.data(), streams.data(), accum, n, w, h, rows);
-}
-
-/* ---- test hook (tests/test_reduce_cpu.py; declared nowhere but here and in the test) --------------------------
- * Runs the exchange logic above over a FAKE RCCL table that writes every call into `log` as one line of text,
- * with no GPU and no librccl: mode 0 = reduce_accum_impl, 1 = reduce_scatter_impl.  The fake state (communicator
- * cache) lives across calls until `reset` is non-zero, so that a test can see communicators being reused for the
- * same device list and replaced for another.  fail_at >= 0 makes the fail_at-th ncclReduce of the call fail.
- * Buffers are fake too: rank i's buffer is the address base + i * 2^32, only ever printed as offsets. */
-namespace {
-std::string* g_fake_log = nullptr;
-int g_fake_reduce_calls = 0, g_fake_fail_at = -1, g_fake_next_comm = 0, g_fake_device = -1;
-void fake_say(const std::string& s) { if (g_fake_log) { *g_fake_log += s; *g_fake_log += '\n'; } }
-ncclResult_t fake_init(ncclComm_t* comms, int n, const int* devs)
-{
-    std::string s = "init";
-    for (int i = 0; i < n; ++i) { comms[i] = (ncclComm_t)(uintptr_t)(0x1000 + ++g_fake_next_comm); s += " dev" + std::to_string(devs[i]) + "=comm" + std::to_string(g_fake_next_comm); }
-    fake_say(s);
-    return ncclSuccess;
-}
-ncclResult_t fake_destroy(ncclComm_t c) { fake_say("destroy comm" + std::to_string((int)((uintptr_t)c - 0x1000))); return ncclSuccess; }
-ncclResult_t fake_group_start() { fake_say("group_start"); return ncclSuccess; }
-ncclResult_t fake_group_end() { fake_say("group_end"); return ncclSuccess; }
-ncclResult_t fake_reduce(const void* src, void* dst, size_t count, ncclDataType_t dt, ncclRedOp_t op, int root, ncclComm_t c, hipStream_t st)
-{
-    const uintptr_t a = (uintptr_t)src;
-    fake_say("reduce dev" + std::to_string(g_fake_device) + " comm" + std::to_string((int)((uintptr_t)c - 0x1000)) + " rank_buf" + std::to_string((int)(a >> 32) - 1) +
-             " off" + std::to_string((unsigned long long)(a & 0xffffffffull) / sizeof(float)) + " count" + std::to_string((unsigned long long)count) +
-             " root" + std::to_string(root) + " stream" + std::to_string((int)(uintptr_t)st) + (src == dst ? " inplace" : " COPY") +
-             (dt == ncclFloat && op == ncclSum ? " f32sum" : " WRONGTYPE"));
-    return g_fake_reduce_calls++ == g_fake_fail_at ? ncclInternalError : ncclSuccess;
-}
-const char* fake_error_string(ncclResult_t) { return "fake failure"; }
-hipError_t fake_set_device(int d) { g_fake_device = d; return hipSuccess; }
-RcclState g_fake_state;
-}  // namespace
-
-extern "C" int rt_debug_reduce_with_fake(int mode, const int* devices, int n, unsigned long long count, int root, int w, int h, int* rows,
-                                         int null_buffer, int fail_at, int reset, char* log, int log_cap)
-{
-    std::lock_guard<std::mutex> lock(g_rccl_mutex);
-    if (reset) { g_fake_state = RcclState(); g_fake_next_comm = 0; }
-    RcclOps& o = g_fake_state.ops;
-    o.CommInitAll = fake_init; o.CommDestroy = fake_destroy; o.GroupStart = fake_group_start; o.GroupEnd = fake_group_end;
-    o.Reduce = fake_reduce; o.GetErrorString = fake_error_string; o.SetDevice = fake_set_device;
-    std::string text;
-    g_fake_log = &text;
-    g_fake_reduce_calls = 0;
-    g_fake_fail_at = fail_at;
-    std::vector<float*> bufs((size_t)(n > 0 ? n : 0));
-    std::vector<hipStream_t> streams(bufs.size());
-    for (size_t i = 0; i < bufs.size(); ++i) {
-        bufs[i] = (int)i == null_buffer ? nullptr : (float*)(uintptr_t)((i + 1) << 32);
-        streams[i] = (hipStream_t)(uintptr_t)(100 + i);
-    }
-    const int rc = mode == 0 ? reduce_accum_impl(g_fake_state, devices, streams.data(), bufs.data(), n, count, root)
-                             : reduce_scatter_impl(g_fake_state, devices, streams.data(), bufs.data(), n, w, h, rows);
-    g_fake_log = nullptr;
-    if (log && log_cap > 0) { std::strncpy(log, text.c_str(), (size_t)log_cap - 1); log[log_cap - 1] = 0; }
-    return rc;
+    return rt_reduce_scatter_lists(devices.data(), streams.data(), accum, n, w, h, rows);
 }
 
 extern "C" int rt_synchronize(rt_ctx* c)
@@ -1360,6 +1221,8 @@ extern "C" int rt_get_counters(rt_ctx* c, rt_counters* out)
     out->last_render_ms = c->last_ms;
     out->render_launches = c->launches;
     out->last_integrator = (uint32_t)c->last_integrator;
+    out->wf_pools = (uint32_t)c->last_wf_pools;
+    out->wf_streams_found = c->wf_n_streams < 0 ? 0u : (uint32_t)c->wf_n_streams;
     return RT_OK;
 }
 

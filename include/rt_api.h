@@ -54,7 +54,10 @@ typedef struct rt_counters {
     double   last_render_ms;  /* HIP-event time of the most recent render kernel */
     uint32_t render_launches;
     uint32_t last_integrator; /* form the most recent render call ran in: RT_INTEGRATOR_MEGAKERNEL or _WAVEFRONT; 0 = none yet */
-} rt_counters;
+    uint32_t wf_pools;        /* pools the most recent wavefront call ran as (3 by default; fewer when the context found fewer
+                                 streams that really run side by side: about -10 % in rate); 0 = no wavefront call yet */
+    uint32_t wf_streams_found;/* streams the context found to overlap when it looked (once, at its first wavefront call) */
+} rt_counters;                /* 48 bytes */
 
 const char* rt_last_error(void);
 
@@ -111,6 +114,7 @@ typedef struct rt_scatter_record {
     float   emitted[3];
     uint32_t pad;
 } rt_scatter_record;       /* 60 bytes */
+/* materials_dev[i] outside the scene's material table: out[i].ok = -1, everything else 0 (never followed). */
 int  rt_shade_rays(rt_ctx* c, int n, const float* rays7_dev, const float* recs9_dev, const int32_t* materials_dev,
                    const uint32_t* psb3_dev, uint64_t seed, rt_scatter_record* out_dev);
 /* rgb_dev[3 i ..] = value(u, v, p) of texture `texture` for uvp5_dev[5 i ..] = (u, v, p[3]) */
@@ -190,6 +194,10 @@ int  rt_flat_program_split(const rt_flat_scene* flat, uint32_t* out_words, int c
                            int* n_groups);
 /* sizes of the device BVHs: two-box nodes, four-box nodes, traversal stack entries each needs */
 int  rt_flat_bvh_stats(const rt_flat_scene* flat, int* nodes2, int* depth2, int* nodes4, int* depth4);
+/* how many child slots of the four-box nodes hold ONE item behind that item's own rt_object::bmin/bmax (a leaf is
+ * opened that way only when its items' bounds are finite, ordered and inside the leaf's box; stale bounds in a
+ * caller's table leave the leaf whole), or a negative rt_status */
+int  rt_flat_bvh4_single_refs(const rt_flat_scene* flat);
 
 /* ---- image output (replaces the quantise loop of main(), main.cu:668-697) ---- */
 /* rgb (host, W*H*3, row 0 = bottom) -> 8-bit, rows flipped to top-down, int(255.99*c) clamped to

@@ -33,6 +33,7 @@ def test_struct_layouts(binding):
     assert C.sizeof(binding.RtCamera) == 96          # same members as the reference Camera
     assert C.sizeof(binding.RtBvhNode) == 32
     assert C.sizeof(binding.RtHitRecord) == 52
+    assert C.sizeof(binding.RtCounters) == 48
     assert np.dtype(binding.HIT_DTYPE).itemsize == 52
 
 
@@ -108,6 +109,43 @@ def test_from_flat_round_trip_and_validation(binding, oracle_mod):
     f.n_bvh_items = keep
     assert binding.lib().rt_scene_from_flat(sc.flat, C.byref(h5)) == 0
     binding.lib().rt_scene_destroy(h5)
+
+
+def test_stale_object_bounds_keep_leaves_whole(binding):
+    """rt_pack_bvh4 opens a two-item leaf into one child per item behind the ITEM's rt_object::bmin/bmax.  A caller's
+    flat table may carry right node boxes and unset object bounds: such a leaf must stay whole (behind the node's box),
+    or the wavefront form would silently lose hits the megakernel's binary tree finds"""
+    lib = binding.lib()
+    sc = binding.Scene("tri_mesh", 32, 24, 2000)
+    f = sc.flat.contents
+    opened = lib.rt_flat_bvh4_single_refs(sc.flat)
+    assert opened > 100
+    items = [f.bvh_items[i] for i in range(f.n_bvh_items)]
+    keep = [(tuple(f.objects[i].bmin), tuple(f.objects[i].bmax)) for i in items]
+    for case in ("zero", "nan", "outside"):
+        for i in items:
+            o = f.objects[i]
+            for a in range(3):
+                if case == "zero":
+                    o.bmin[a] = o.bmax[a] = 0.0
+                elif case == "nan":
+                    o.bmin[a] = float("nan")
+                else:
+                    o.bmin[a] -= 50.0
+        left = lib.rt_flat_bvh4_single_refs(sc.flat)
+        n2, d2, n4, d4 = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        assert lib.rt_flat_bvh_stats(sc.flat, C.byref(n2), C.byref(d2), C.byref(n4), C.byref(d4)) == 0     # still covers every item once
+        for i, (lo, hi) in zip(items, keep):
+            for a in range(3):
+                f.objects[i].bmin[a], f.objects[i].bmax[a] = lo[a], hi[a]
+        assert left < opened // 2, (case, left, opened)     # only leaves the builder itself made of one item remain
+    assert lib.rt_flat_bvh4_single_refs(sc.flat) == opened
+
+
+def test_test_hooks_are_not_in_the_product_library(binding):
+    lib = binding.load_library()
+    assert not hasattr(lib, "rt_debug_reduce_with_fake")
+    assert hasattr(binding.load_reduce_test_library(), "rt_debug_reduce_with_fake")
 
 
 def test_builtin_scenes_are_built_once_per_process_and_thread_safe(binding, oracle_mod):

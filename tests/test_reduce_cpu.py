@@ -1,5 +1,5 @@
-"""The multi-GPU exchange logic of rt_reduce_accum / rt_reduce_scatter_rows (csrc/rt_kernels.hip) driven through an
-injected fake RCCL table: no machine available to the build has two GPUs, so the argument checks, the communicator
+"""The multi-GPU exchange logic of rt_reduce_accum / rt_reduce_scatter_rows (csrc/rt_reduce.cpp) driven through an
+injected fake RCCL table (rt_debug_reduce_with_fake: only in librt_reduce_test.so, the -DRT_TEST_HOOKS build of that file): no machine available to the build has two GPUs, so the argument checks, the communicator
 cache and the exact sequence of grouped ncclReduce calls are pinned here, on the CPU, call by call."""
 import ctypes as C
 
@@ -17,7 +17,7 @@ def run(lib, mode, devices, count=0, root=0, w=0, h=0, null_buffer=-1, fail_at=-
 
 
 def test_reduce_accum_call_sequence_and_communicator_cache(binding):
-    lib = binding.lib()
+    lib = binding.load_reduce_test_library()
     rc, log, _ = run(lib, 0, [0, 1, 2, 3], count=3 * 64 * 48, root=0, reset=True)
     assert rc == 0
     assert log[0] == "init dev0=comm1 dev1=comm2 dev2=comm3 dev3=comm4"
@@ -41,7 +41,7 @@ def test_reduce_accum_call_sequence_and_communicator_cache(binding):
 
 
 def test_reduce_accum_refuses_bad_arguments_before_touching_rccl(binding):
-    lib = binding.lib()
+    lib = binding.load_reduce_test_library()
     for kw in (dict(devices=[0, 1], count=0, root=0), dict(devices=[0, 1], count=8, root=2), dict(devices=[0, 1], count=8, root=-1),
                dict(devices=[], count=8, root=0), dict(devices=[0, 0], count=8, root=0), dict(devices=[0, 1, 0], count=8, root=0),
                dict(devices=[0, 1], count=8, root=0, null_buffer=1)):
@@ -57,7 +57,7 @@ def binding_err_arg():
 
 
 def test_a_failing_reduce_closes_the_group_and_reports(binding):
-    lib = binding.lib()
+    lib = binding.load_reduce_test_library()
     rc, log, _ = run(lib, 0, [0, 1, 2], count=5, root=0, fail_at=1, reset=True)
     assert rc == -5                                                     # RT_ERR_RCCL
     assert log[-1] == "group_end" and sum(s.startswith("reduce") for s in log) == 2     # stopped at the failure, group closed
@@ -68,7 +68,7 @@ def test_a_failing_reduce_closes_the_group_and_reports(binding):
 
 
 def test_reduce_scatter_rows_bands(binding):
-    lib = binding.lib()
+    lib = binding.load_reduce_test_library()
     W, H = 7, 10
     rc, log, rows = run(lib, 1, [0, 1, 2], w=W, h=H, reset=True)
     assert rc == 0 and rows == [0, 3, 6, 10]                            # bands may differ in height

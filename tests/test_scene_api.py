@@ -201,6 +201,38 @@ def test_user_scene_source_in_reference_style_compiles(tmp_path):
     assert n_prims == 12 + 64                     # leaves: 12 in the list (medium counts) + 64 in the group
 
 
+def test_camera_has_the_reference_public_members(tmp_path):
+    """Camera.cuh:47-49 declares lowerLeftCorner, horizontal, vertical, origin, u, v, w, lensRadius, time0, time1 as public
+    data: a user program that reads them compiles, and sees bit for bit what the lowered camera block holds"""
+    body = textwrap.dedent('''
+        #include <cstring>
+        __device__ inline void camScene(Hitable** dList, Hitable** dWorld, Camera** dCamera, int width, int height,
+                                        ImageTexture** texture, curandState* randState)
+        {
+            dList[0] = new Sphere(Vector3(0, 0, 0), 1.f, new Lambert(new ConstantTexture(Vector3(.5f, .5f, .5f))));
+            *dWorld = new HitableList(dList, 1);
+            *dCamera = new Camera(Vector3(13, 2, 3), Vector3(0, .3f, -1), Vector3(0, 1, 0), 27.5f, float(width) / float(height), 0.1f, 9.7f, 0.25f, 1.5f);
+        }
+        static int same(const Vector3& a, const float* b) { return std::memcmp(a.e, b, 12) == 0; }
+    ''')
+    call = textwrap.dedent('''
+        camScene(dList, &world, &cam, 400, 225, &img, &rs);
+        {
+            rt::FlatScene fs; std::string e;
+            if (!rt::lower(world, cam, rt::LowerOptions(), fs, e)) return 4;
+            const rt_camera& c = fs.view.camera;
+            Camera* k = cam;
+            int ok = same((*&k)->origin, c.origin) && same(k->lowerLeftCorner, c.lower_left) && same(k->horizontal, c.horizontal)
+                  && same(k->vertical, c.vertical) && same(k->u, c.u) && same(k->v, c.v) && same(k->w, c.w)
+                  && k->lensRadius == c.lens_radius && k->time0 == c.time0 && k->time1 == c.time1
+                  && k->lensRadius == 0.05f && k->time0 == 0.25f && k->time1 == 1.5f && k->origin.x() == 13.f;
+            if (!ok) { std::cout << "MEMBERS DIFFER\\n"; return 5; }
+        }
+    ''')
+    out = compile_and_run(tmp_path, body, call)
+    assert out[-1] == 1 and "MEMBERS" not in out
+
+
 @pytest.mark.skipif(not os.path.exists(REF_MAIN), reason="reference sources are only present in the build container")
 def test_reference_scene_functions_compile_unchanged(tmp_path):
     """scene1..scene7 are taken from the reference's main.cu AT TEST TIME (nothing is stored in this
