@@ -61,3 +61,36 @@ def test_two_rank_reduce_equals_single_render(tmp_path, binding, oracle):
     # same samples, summed as (0..3)+(4..6) instead of 0..6: equal up to fp32 summation order
     assert np.allclose(got, full, rtol=1e-5, atol=1e-6)
     assert got.sum() > 0
+
+
+def test_bench_step_ranges_weak_and_strong():
+    """bench.py's sample ranges per (step, rank): weak = every rank its own `spp` fresh samples, strong = the step's `spp`
+    samples cut over the ranks (BASELINE configs[3], "spp-sharded"); in both, no sample index is rendered twice"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rt_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for world in (1, 2, 4, 8):
+        for scaling, per_step in (("weak", 32 * world), ("strong", 32)):
+            seen = []
+            for k in range(3):
+                r = [bench.step_sample_range(scaling, k, rank, world, 32) for rank in range(world)]
+                assert sum(e - b for b, e in r) == per_step
+                seen += [i for b, e in r for i in range(b, e)]
+            assert len(seen) == len(set(seen)) == 3 * per_step and min(seen) == 0 and max(seen) == 3 * per_step - 1
+    assert bench.DEFAULT_SCALING["tri_mesh"] == "strong" and bench.DEFAULT_SCALING["cornell"] == "weak"
+
+
+def test_bench_starts_its_own_ranks_and_passes_their_exit_code():
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts torch.distributed.run as a child and
+    hands on its exit code; in this container there is no GPU, so the ranks refuse to run and the parent fails with them,
+    printing no JSON line"""
+    env = dict(os.environ, RT_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-extras",
+                        "--no-cpu-baseline", "--width", "16", "--height", "16", "--spp", "2"], capture_output=True, text=True, timeout=300, env=env)
+    import torch
+    if torch.cuda.is_available():
+        assert r.returncode == 0 and r.stdout.count("{\"metric\"") == 1
+    else:
+        assert r.returncode != 0 and "no GPU visible" in r.stderr and not r.stdout.strip()

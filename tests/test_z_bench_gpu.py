@@ -48,14 +48,21 @@ def test_two_rank_flow_rehearsal():
     W, H, spp = 64, 48, 8
     env = dict(os.environ, RT_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     common = ["--width", str(W), "--height", str(H), "--spp", str(spp), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
+    # the plain command line, as the round-end driver may give it: no outer launcher, bench.py starts the ranks itself
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common,
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]       # ONE JSON line and nothing else on stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["image_finite"] and "REHEARSAL" in j["config"]["parallelism"]
+    # ... and under the launcher (the contract's form): same line
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common,
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["image_finite"] and "REHEARSAL" in j["config"]["parallelism"]
+    jl = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert jl["n_gpus"] == 2 and abs(jl["image_mean"] - j["image_mean"]) <= 1e-7
     # the last step: rank r renders samples [(1 * 2 + r) * spp, + spp); together [2 spp, 4 spp) = one direct render
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + ["--width", str(W), "--height", str(H), "--spp", str(2 * spp), "--steps", "1",
                         "--warmup", "1", "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=300)
@@ -63,3 +70,17 @@ def test_two_rank_flow_rehearsal():
     j1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])
     assert abs(j1["image_mean"] - j["image_mean"]) <= 1e-5       # same samples, summed in another order
     assert j["samples_per_s"] > 0 and abs(j["rays_per_sample"] - j1["rays_per_sample"]) < 1e-9
+    # strong scaling (BASELINE configs[3]: "spp-sharded"): the total stays 2 spp... 16 samples, rank r renders
+    # sample_range(r, 2, 16) of them; the image is the one GPU's image of the same 16 samples
+    rs = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scaling", "strong", "--workload", "tri_mesh", "--param", "20000",
+                         "--width", str(W), "--height", str(H), "--spp", "16", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras"],
+                        capture_output=True, text=True, timeout=300, env=env)
+    assert rs.returncode == 0, rs.stderr[-2000:]
+    js = json.loads(rs.stdout.splitlines()[-1])
+    r1s = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tri_mesh", "--param", "20000", "--width", str(W), "--height", str(H),
+                          "--spp", "16", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=300)
+    assert r1s.returncode == 0, r1s.stderr[-2000:]
+    j1s = json.loads(r1s.stdout.splitlines()[-1])
+    assert js["scaling"] == "strong" and j1s["scaling"] == "strong" and js["config"]["spp_total"] == 16 and js["config"]["spp_per_gpu"] == 8
+    assert abs(js["image_mean"] - j1s["image_mean"]) <= 1e-5 and abs(js["rays_per_sample"] - j1s["rays_per_sample"]) < 1e-9
+    assert js["config"]["integrator"] == "wavefront"

@@ -34,15 +34,69 @@ __global__ __launch_bounds__(256, WAVES) void gather_kernel(const float4* __rest
     out[tid] = acc;
 }
 
-struct Mode { const char* name; int nv, row_bytes, waves, dependent; };
+// Cooperative form of the same gather (round 3): the lanes of a wave still want one row each, but the row of lane j is
+// fetched by Q adjacent lanes, 16 bytes each (Q = 4 for a 64-B row, 8 for a 128-B row), so that one load instruction
+// touches 64 / Q rows with Q lanes per cache line instead of 64 rows with one lane per line; Q instructions fetch all 64
+// rows.  The address unit of a CU takes about one DIVERGENT 16-byte lane per clock; this asks whether lanes that share a
+// line share the clock.  LDS = 1: every piece then goes through LDS (ds_write_b128 where its owner expects it, then the
+// owner reads its row with NV ds_read_b128), which is what a traversal kernel would have to pay to get its row back.
+template <int Q, int WAVES, int LDS>
+__global__ __launch_bounds__(256, WAVES) void gather_coop_kernel(const float4* __restrict__ table, uint32_t n_rows, int iters,
+                                                                 int dependent, float* __restrict__ out)
+{
+    __shared__ float4 stage[LDS ? 256 * Q : 1];
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+    const int lane = (int)(threadIdx.x & 63u), piece = lane & (Q - 1), sub = lane / Q;      // sub: which of the 64 / Q rows of an instruction
+    float4* wave_stage = stage + (LDS ? (threadIdx.x & ~63u) * Q : 0);
+    uint32_t x = tid * 2654435761u + 12345u;
+    float acc = 0.f;
+    for (int i = 0; i < iters; ++i) {
+        x = x * 1664525u + 1013904223u;
+        const uint32_t r = __umulhi(x, n_rows);                 // the row THIS lane wants
+        float4 v[Q];
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+            const int owner = k * (64 / Q) + sub;               // the lane whose row this instruction's group `sub` fetches
+            const uint32_t ro = (uint32_t)__builtin_amdgcn_ds_bpermute(owner << 2, (int)r);
+            v[k] = table[(size_t)ro * Q + piece];
+        }
+        if (LDS) {
+#pragma unroll
+            for (int k = 0; k < Q; ++k) wave_stage[(k * (64 / Q) + sub) * Q + piece] = v[k];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int k = 0; k < Q; ++k) v[k] = wave_stage[lane * Q + k];
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int k = 0; k < Q; ++k) acc += v[k].x + v[k].w;
+        if (dependent) x ^= __float_as_uint(acc) & 0xffu;
+    }
+    out[tid] = acc;
+}
+
+struct Mode { const char* name; int nv, row_bytes, waves, dependent; int coop = 0, lds = 0; };
 static const Mode MODES[] = {
     {"leaf64_dep_5w", 4, 64, 5, 1}, {"node112_dep_5w", 7, 128, 5, 1}, {"leaf64_dep_8w", 4, 64, 8, 1}, {"node112_dep_8w", 7, 128, 8, 1},
     {"leaf64_indep_8w", 4, 64, 8, 0}, {"node112_indep_8w", 7, 128, 8, 0},
+    {"coop64_dep_5w", 4, 64, 5, 1, 1, 0}, {"coop128_dep_5w", 8, 128, 5, 1, 1, 0},
+    {"coop64_lds_dep_5w", 4, 64, 5, 1, 1, 1}, {"coop128_lds_dep_5w", 8, 128, 5, 1, 1, 1},
+    {"coop64_dep_8w", 4, 64, 8, 1, 1, 0}, {"coop128_dep_8w", 8, 128, 8, 1, 1, 0},
 };
 
 static void launch(const Mode& m, const float4* table, uint32_t n_rows, int iters, float* out, int blocks)
 {
     const int row_f4 = m.row_bytes / 16;
+    if (m.coop) {
+#define LC(Q, W, LD) gather_coop_kernel<Q, W, LD><<<blocks, 256>>>(table, n_rows, iters, m.dependent, out)
+        if (m.nv == 4 && m.waves == 5 && !m.lds) LC(4, 5, 0); else if (m.nv == 8 && m.waves == 5 && !m.lds) LC(8, 5, 0);
+        else if (m.nv == 4 && m.lds) LC(4, 5, 1); else if (m.nv == 8 && m.lds) LC(8, 5, 1);
+        else if (m.nv == 4) LC(4, 8, 0); else LC(8, 8, 0);
+#undef LC
+        return;
+    }
 #define L(NV, W) gather_kernel<NV, W><<<blocks, 256>>>(table, n_rows, row_f4, iters, m.dependent, out)
     if (m.nv == 4 && m.waves == 5) L(4, 5); else if (m.nv == 7 && m.waves == 5) L(7, 5);
     else if (m.nv == 4) L(4, 8); else L(7, 8);
