@@ -80,7 +80,7 @@ HIT_DTYPE = [("hit", "<i4"), ("prim", "<i4"), ("t", "<f4"), ("u", "<f4"), ("v", 
 EXPORTS = [
     "rt_last_error", "rt_scene_create_builtin", "rt_scene_from_flat", "rt_scene_flat",
     "rt_scene_default_background", "rt_scene_destroy", "rt_ctx_create", "rt_ctx_destroy",
-    "rt_scene_upload", "rt_trace_rays", "rt_trace_primary", "rt_shade_rays", "rt_texture_values", "rt_render_accumulate", "rt_render_accumulate_window", "rt_render_accumulate_noalloc", "rt_resolve",
+    "rt_scene_upload", "rt_trace_rays", "rt_trace_rays_wavefront", "rt_trace_primary", "rt_shade_rays", "rt_texture_values", "rt_render_accumulate", "rt_render_accumulate_window", "rt_render_accumulate_noalloc", "rt_resolve",
     "rt_ctx_set_integrator", "rt_reduce_accum", "rt_reduce_scatter_rows", "rt_synchronize", "rt_get_counters", "rt_reset_counters", "rt_quantise_rgb8", "rt_write_ppm", "rt_write_png", "rt_read_ppm", "rt_free_pixels", "rt_flat_features", "rt_flat_program", "rt_flat_program_split", "rt_flat_bvh_stats", "rt_flat_bvh4_single_refs",
 ]
 
@@ -107,6 +107,7 @@ def load_library(path=LIB_PATH):
     lib.rt_ctx_destroy.restype = None
     lib.rt_scene_upload.argtypes = [vp, C.POINTER(RtFlatScene)]
     lib.rt_trace_rays.argtypes = [vp, i32, vp, f32, f32, vp]
+    lib.rt_trace_rays_wavefront.argtypes = [vp, i32, vp, vp]
     lib.rt_trace_primary.argtypes = [vp, i32, i32, f32, f32, vp, vp]
     lib.rt_shade_rays.argtypes = [vp, i32, vp, vp, vp, vp, u64, vp]
     lib.rt_texture_values.argtypes = [vp, i32, i32, vp, vp]
@@ -209,6 +210,18 @@ class Context:
         out = torch.zeros(n * 52, dtype=torch.uint8, device=rays.device)
         torch.cuda.synchronize(rays.device)
         _check(lib().rt_trace_rays(self.handle, n, rays.data_ptr(), tmin, tmax, out.data_ptr()), "rt_trace_rays")
+        self.synchronize()
+        return np.frombuffer(out.cpu().numpy().tobytes(), dtype=np.dtype(HIT_DTYPE))
+
+    def trace_rays_wavefront(self, rays):
+        """closest hits through the wavefront form's intersect kernel; tmin = .001, tmax = FLT_MAX"""
+        import numpy as np
+        import torch
+        assert rays.is_cuda and rays.dtype == torch.float32 and rays.is_contiguous() and rays.shape[-1] == 7
+        n = rays.shape[0]
+        out = torch.zeros(n * 52, dtype=torch.uint8, device=rays.device)
+        torch.cuda.synchronize(rays.device)
+        _check(lib().rt_trace_rays_wavefront(self.handle, n, rays.data_ptr(), out.data_ptr()), "rt_trace_rays_wavefront")
         self.synchronize()
         return np.frombuffer(out.cpu().numpy().tobytes(), dtype=np.dtype(HIT_DTYPE))
 

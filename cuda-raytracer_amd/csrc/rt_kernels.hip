@@ -24,6 +24,7 @@
 #include "rt_device.h"
 #include "rt_host.h"
 #include "rt_wavefront.h"
+#include "rt_wavefront2.h"
 #include "rt_reduce.h"
 
 /* feature sets the render kernel is compiled for (rt_host.h RT_F_*); a scene runs on the first one
@@ -46,9 +47,12 @@
 #ifndef RT_WF_SLOTS
 #define RT_WF_SLOTS (1u << 27)
 #endif
-#define RT_N_COUNTERS 16        /* rays, samples, then diagnostic slots */
+#define RT_N_COUNTERS 32        /* rays, samples, then diagnostic slots */
 #define WF_MAX_POOLS 4
 #define WF_POOL_COUNT_WORDS (9 * 32)   /* per pool: one 128-B line of queue lengths + legacy head, then a line per band head */
+#ifndef WF_KERNEL_DEFAULT
+#define WF_KERNEL_DEFAULT 1     /* the intersect kernel wavefront renders use unless RT_WF_KERNEL says otherwise (wf_pick_kernel) */
+#endif
 #ifndef WF_POOLS_DEFAULT
 #define WF_POOLS_DEFAULT 3
 #endif
@@ -415,7 +419,7 @@ struct rt_ctx {
     bool have_scene = false;
     bool has_bvh = false;
     int n_bvh_items = 0;
-    int n_textures = 0, n_materials = 0;
+    int n_textures = 0, n_materials = 0, n_objects = 0;
     uint32_t features = 0;    /* RT_F_* of the uploaded scene */
     int integrator = RT_INTEGRATOR_AUTO;
     int last_integrator = 0;          /* form the latest render call ran in (rt_counters) */
@@ -597,6 +601,7 @@ extern "C" int rt_scene_upload(rt_ctx* c, const rt_flat_scene* s)
     c->n_bvh_items = s->n_bvh_items;
     c->n_textures = s->n_textures;
     c->n_materials = s->n_materials;
+    c->n_objects = s->n_objects;
     c->stack_depth = stack_depth < 1 ? 1 : stack_depth;
     c->have_scene = true;
     return RT_OK;
@@ -763,6 +768,20 @@ template <uint32_t V>
 static int wf_run_part(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t s1, uint32_t k0, uint32_t k1, int max_depth,
                        int background, float* accum);
 
+/* which intersect kernel: 2 = staged rays + queued leaves (rt_wavefront2.h), 1 = the first design (rt_wavefront.h); the
+ * second packs a leaf item and a lane into 32 bits, an object and a group ordinal into the mailbox word, and its
+ * all-feature variants have a shorter stack.  RT_WF_KERNEL in the environment overrides (A/B measurements). */
+template <uint32_t V>
+static int wf_pick_kernel(const rt_ctx* c)
+{
+    const bool fits2 = c->n_bvh_items < (1 << WF2_ITEM_BITS) && c->n_objects < (1 << WF2_OBJ_BITS) - 1 && c->n_wf_groups <= WF2_MAX_GROUPS;
+    int kernel = WF_KERNEL_DEFAULT == 2 && fits2 ? 2 : 1;
+    if (const char* e = std::getenv("RT_WF_KERNEL")) { const int v = std::atoi(e); if (v == 1 || (v == 2 && fits2)) kernel = v; }
+    if (c->stack4 > wf2_lds_stack(V & ~RT_F_NOISE) + wf2_ovf(V & ~RT_F_NOISE)) kernel = 1;      /* a tree deeper than this variant's stack */
+    if (!wf2_built(V)) kernel = 1;
+    return kernel;
+}
+
 /* A call is normally ONE part.  While the queue was appended to in the order in which the logic kernel's blocks happened
  * to finish, it drifted away from slot order over hundreds of iterations and long calls were cut into parts of four
  * samples per stream, each starting from a fresh queue (final scene 3840x2160 x 4096 spp as one call: 3.14 Grays/s whole,
@@ -815,6 +834,9 @@ static int wf_run_part(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t 
      * lanes.  Measured at 1080p (tools/refill_sweep.py), Grays/s at 16 / 24 / 32 / 40 / 48 / 56 idle lanes: final scene
      * (11 plain records) 2.78 / 2.93 / 3.01 / 3.04 / 3.01 / 2.90; 1M triangles (1 record) 2.08 / 2.10 / 2.12 / 2.12 / 2.12 / 2.09 */
     W.refill_min = 40;
+    const int kernel = wf_pick_kernel<V>(c);
+    if (kernel == 2) W.refill_min = 12;        /* handing over a staged ray is a few LDS reads */
+    W.bare = 0;
     /* XCD-affine claims of the queue (rt_wavefront.h): with the queue in slot order they raise the intersect kernel's L2
      * hit rate on the 1M-triangle scene from 30 % to 56 % (L2 misses x 0.61) for +1 % in rate there and +-0 on the final
      * scene: the misses were one of three limits that sit close together.  RT_WF_AFFINE=0 turns them off. */
@@ -823,7 +845,8 @@ static int wf_run_part(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t 
     /* RT_WF_REFILL in the environment overrides it (how those figures were measured) */
     if (const char* e = std::getenv("RT_WF_REFILL")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) W.refill_min = v; }
     if (c->stack4 > WF_LDS_STACK + WF_OVF_STACK) { rt_set_error("wavefront integrator: BVH deeper than its traversal stack"); return RT_ERR_UNSUPPORTED; }
-    const size_t lds = (size_t)(c->stack4 < WF_LDS_STACK ? c->stack4 : WF_LDS_STACK) * RT_BLOCK * sizeof(int);
+    const int lds_stack = kernel == 2 ? wf2_lds_stack(V & ~RT_F_NOISE) : WF_LDS_STACK;
+    const size_t lds = (size_t)(c->stack4 < lds_stack ? c->stack4 : lds_stack) * RT_BLOCK * sizeof(int);
     /* Pools.  The slots are cut into three pools by sample stream and each pool runs its own intersect / logic loop
      * on a stream of its own, with a persistent intersect grid of a third of the size: while one pool's intersect
      * launch drains (its waves waiting for their last rays) or its logic kernel waits on memory, the other pools'
@@ -906,7 +929,8 @@ static int wf_run_part(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t 
                     const unsigned blocks = (P.known + RT_BLOCK - 1) / RT_BLOCK;
                     const unsigned iblocks = blocks < iblocks_max ? blocks : iblocks_max;
                     const unsigned lblocks = (P.known + WF_SPAN - 1) / WF_SPAN;
-                    wf_intersect_kernel<(V & ~RT_F_NOISE)><<<dim3(iblocks), RT_BLOCK, lds, P.st>>>(c->ds, P.W, P.cur, k0, k1, c->d_counters);   /* reads no texture */
+                    if constexpr (wf2_built(V)) { if (kernel == 2) wf_intersect2_kernel<(V & ~RT_F_NOISE)><<<dim3(iblocks), RT_BLOCK, lds, P.st>>>(c->ds, P.W, P.cur, k0, k1, c->d_counters); }
+                    if (kernel != 2) wf_intersect_kernel<(V & ~RT_F_NOISE)><<<dim3(iblocks), RT_BLOCK, lds, P.st>>>(c->ds, P.W, P.cur, k0, k1, c->d_counters);   /* reads no texture */
                     if (background == RT_BG_BLACK)
                         wf_logic_kernel<V, RT_BG_BLACK><<<dim3(lblocks), RT_BLOCK, 0, P.st>>>(c->ds, P.W, P.cur, w, h, s1, k0, k1, max_depth);
                     else
@@ -941,6 +965,88 @@ static int wf_run_part(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t 
     wf_finalize_kernel<<<dim3((n_pixels + RT_BLOCK - 1) / RT_BLOCK), RT_BLOCK, 0, c->stream>>>(W, accum);
     HIPCHK(hipGetLastError());
     return RT_OK;
+}
+
+/* ---- rt_trace_rays_wavefront: caller-supplied rays through the wavefront form's own traversal ---------------------- */
+__global__ __launch_bounds__(RT_BLOCK) void wf_trace_fill_kernel(WfState W, int n, const float* __restrict__ rays)
+{
+    const int i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float* q = rays + 7 * (size_t)i;
+    W.ray_o[i] = make_float4(q[0], q[1], q[2], q[6]);
+    W.ray_d[i] = make_float4(q[3], q[4], q[5], __uint_as_float(0u));
+    W.att[i] = make_float4(1.f, 1.f, 1.f, __uint_as_float(0u));
+    W.hit[i] = make_float4(FLT_MAX, __int_as_float(-1), __int_as_float(-1), __int_as_float(0));
+    W.queue[0][i] = (uint32_t)i;
+}
+template <uint32_t F>
+__global__ __launch_bounds__(RT_BLOCK) void wf_trace_out_kernel(DScene S, WfState W, int n, const float* __restrict__ rays, rt_hit_record* __restrict__ out)
+{
+    const int i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float* q = rays + 7 * (size_t)i;
+    DRay r;
+    r.o = mk(q[0], q[1], q[2]); r.d = mk(q[3], q[4], q[5]); r.time = q[6];
+    const float4 h4 = W.hit[i];
+    HitLite hl = {h4.x, __float_as_int(h4.y), __float_as_int(h4.z), __float_as_int(h4.w)};
+    rt_hit_record o;
+    memset(&o, 0, sizeof o);
+    o.prim = -1;
+    if (hl.obj >= 0) {
+        HitRec h;
+        rebuild<F, true>(S, r, hl, .001f, h);
+        o.hit = 1; o.prim = h.prim_id; o.t = h.t; o.u = h.u; o.v = h.v;
+        o.p[0] = h.p.x; o.p[1] = h.p.y; o.p[2] = h.p.z;
+        o.n[0] = h.n.x; o.n[1] = h.n.y; o.n[2] = h.n.z;
+        o.front_face = h.front; o.material = h.material;
+    }
+    out[i] = o;
+}
+template <uint32_t V>
+static int wf_trace(rt_ctx* c, int n, const float* rays, rt_hit_record* out)
+{
+    int rc = wf_reserve(c, (size_t)n);
+    if (rc) return rc;
+    WfState W = c->wf;
+    W.n_slots = (uint32_t)n; W.n_pixels = (uint32_t)n; W.streams = 1; W.stream0 = 0;
+    W.win_x0 = W.win_y0 = 0; W.win_w = W.frame_w = (uint32_t)n;
+    W.prog = (const DProg*)c->d_prog_wf; W.groups = (const int*)c->d_wf_groups; W.n_groups = c->n_wf_groups;
+    const int kernel = wf_pick_kernel<V>(c);
+    W.refill_min = kernel == 2 ? 12 : 40;
+    W.affine = 0;
+    W.bare = 1;
+    if (c->stack4 > WF_LDS_STACK + WF_OVF_STACK) { rt_set_error("rt_trace_rays_wavefront: BVH deeper than the traversal stack"); return RT_ERR_UNSUPPORTED; }
+    const int lds_stack = kernel == 2 ? wf2_lds_stack(V & ~RT_F_NOISE) : WF_LDS_STACK;
+    const size_t lds = (size_t)(c->stack4 < lds_stack ? c->stack4 : lds_stack) * RT_BLOCK * sizeof(int);
+    const unsigned blocks = (unsigned)((n + RT_BLOCK - 1) / RT_BLOCK);
+    HIPCHK(hipMemsetAsync(W.count, 0, WF_POOL_COUNT_WORDS * sizeof(uint32_t), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));                  /* the pinned word below may still be read by an earlier call's copy */
+    c->wf_host_count[4 * WF_MAX_POOLS] = (uint32_t)n;
+    HIPCHK(hipMemcpyAsync(W.count, &c->wf_host_count[4 * WF_MAX_POOLS], sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    wf_trace_fill_kernel<<<dim3(blocks), RT_BLOCK, 0, c->stream>>>(W, n, rays);
+    const unsigned iblocks = blocks < 2048u ? blocks : 2048u;
+    if constexpr (wf2_built(V)) { if (kernel == 2) wf_intersect2_kernel<(V & ~RT_F_NOISE)><<<dim3(iblocks), RT_BLOCK, lds, c->stream>>>(c->ds, W, 0, 0u, 0u, c->d_counters + 3); }
+    if (kernel != 2) wf_intersect_kernel<(V & ~RT_F_NOISE)><<<dim3(iblocks), RT_BLOCK, lds, c->stream>>>(c->ds, W, 0, 0u, 0u, c->d_counters + 3);
+    wf_trace_out_kernel<V><<<dim3(blocks), RT_BLOCK, 0, c->stream>>>(c->ds, W, n, rays, out);
+    HIPCHK(hipGetLastError());
+    return RT_OK;
+}
+
+/* No render: a parity hook like rt_trace_rays, through the intersect kernel the wavefront form renders with. */
+extern "C" int rt_trace_rays_wavefront(rt_ctx* c, int n, const float* rays, rt_hit_record* out)
+{
+    int rc = need_scene(c, "rt_trace_rays_wavefront");
+    if (rc) return rc;
+    if (n < 0 || (n && (!rays || !out))) { rt_set_error("rt_trace_rays_wavefront: bad arguments"); return RT_ERR_ARG; }
+    if (n == 0) return RT_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const char* force = std::getenv("RT_FORCE_VARIANT");          /* test hook, as in the render calls */
+    const bool force_all = force && (!std::strcmp(force, "all") || !std::strcmp(force, "list")) && (c->features & ~RT_F_ALL) == 0;
+    return force_all ? wf_trace<RT_F_ALL>(c, n, rays, out)
+           : (c->features & ~RT_V_BVH_TRI) == 0 ? wf_trace<RT_V_BVH_TRI>(c, n, rays, out)
+           : (c->features & ~RT_V_NOTRI) == 0 ? wf_trace<RT_V_NOTRI>(c, n, rays, out)
+           : (c->features & ~RT_F_ALL) == 0   ? wf_trace<RT_F_ALL>(c, n, rays, out)
+                                              : wf_trace<RT_V_NOISE>(c, n, rays, out);
 }
 
 /* Runs of the megakernel.  The sample range is cut into up to 16 runs of >= 64 samples, and a block renders one run each of
@@ -1227,6 +1333,14 @@ extern "C" int rt_get_counters(rt_ctx* c, rt_counters* out)
 }
 
 #ifdef RT_STAMPS
+/* words 16..31 of the counters: the section cycles of wf_intersect2_kernel */
+extern "C" int rt_debug_sections(rt_ctx* c, unsigned long long* out16)
+{
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out16, c->d_counters + 16, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
 extern "C" int rt_debug_stamps(rt_ctx* c, unsigned long long* out12)
 {
     HIPCHK(hipSetDevice(c->device));

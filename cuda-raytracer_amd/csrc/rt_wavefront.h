@@ -46,6 +46,7 @@ struct WfState {
     int n_groups;
     int refill_min;    /* idle lanes that make a refill (and its run over the plain records) worth while */
     int affine;        /* 1: a wave takes its chunks of the queue from the image band of its XCD first (below) */
+    int bare;          /* 1: a bare closest-hit query (rt_trace_rays_wavefront): no RNG, media are ignored as in rt_trace_rays */
 };
 
 /* slot -> pixel: stream k of window pixel p is slot k * n_pixels + p; returns the pixel's index in the FRAME,
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(RT_BLOCK, wf_intersect_waves(F)) void wf_intersect_
                     ++n_rays;
                     /* the plain records of the world list, for all the lanes of this batch together (one scalar
                      * record stream, as in the megakernel's closest_hit), then on to the first BVH group */
-                    scan_program<(F & ~RT_F_BVH)>(S, W.prog, rw, tMin, best, &g, bounce, stack);
+                    scan_program<(F & ~RT_F_BVH)>(S, W.prog, rw, tMin, best, W.bare ? nullptr : &g, bounce, stack);
                     gidx = 0;
                     WF_NEXT_GROUP
                 }

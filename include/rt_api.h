@@ -96,6 +96,12 @@ int  rt_scene_upload(rt_ctx* c, const rt_flat_scene* flat);
 /* ---- closest hit (the body of colour()'s loop, main.cu:56; HitableList::hit) ---- */
 /* n rays of 7 floats (origin, direction, time); media are ignored (no RNG in a bare query) */
 int  rt_trace_rays(rt_ctx* c, int n, const float* rays7_dev, float tmin, float tmax, rt_hit_record* out_dev);
+/* The same query through the traversal the WAVEFRONT form of the integrator renders with (its persistent intersect
+ * kernel over a queue of the n rays: four-wide nodes, staged rays, queued leaves) instead of the megakernel's, so that
+ * its hits can be held against the reference's vectors directly and not only through whole renders.  tmin = .001f and
+ * tmax = FLT_MAX are the integrator's own (main.cu:56) and fixed; media are ignored here too.  Uses the context's
+ * wavefront state: not to be overlapped with a render on the same context. */
+int  rt_trace_rays_wavefront(rt_ctx* c, int n, const float* rays7_dev, rt_hit_record* out_dev);
 /* pinhole-centre primary ray of every pixel: u=(i+s_off)/W, v=(j+t_off)/H, lens offset 0,
  * time=time0; tmin=.001f, tmax=FLT_MAX.  prim_dev/t_dev are W*H, row 0 = bottom. */
 int  rt_trace_primary(rt_ctx* c, int width, int height, float s_off, float t_off,

@@ -16,9 +16,18 @@ pytestmark = pytest.mark.gpu
 UV_ATOL = 2e-6      # device vs host libm in getSphereUV (Sphere.cuh:64-70)
 
 
-def gpu_trace(ctx, rays, tmin=0.001, tmax=FLT_MAX):
+def gpu_trace(ctx, rays, tmin=0.001, tmax=FLT_MAX, via="megakernel"):
+    """closest hits of caller-supplied rays: through the megakernel's traversal (rt_trace_rays) or through the wavefront
+    form's intersect kernel (rt_trace_rays_wavefront; the integrator's own range only)"""
     import torch
-    return ctx.trace_rays(torch.from_numpy(np.ascontiguousarray(rays, np.float32)).cuda(), tmin, tmax)
+    r = torch.from_numpy(np.ascontiguousarray(rays, np.float32)).cuda()
+    if via == "wavefront":
+        assert (tmin, tmax) == (0.001, FLT_MAX)
+        return ctx.trace_rays_wavefront(r)
+    return ctx.trace_rays(r, tmin, tmax)
+
+
+TRAVERSALS = ["megakernel", "wavefront"]
 
 
 def compare_hits(got, exp, types, what, ties_ok=False):
@@ -41,18 +50,20 @@ def compare_hits(got, exp, types, what, ties_ok=False):
     assert np.allclose(got["v"][h][uv], exp["v"][h][uv], rtol=0, atol=UV_ATOL), what + ": v"
 
 
+@pytest.mark.parametrize("via", TRAVERSALS)
 @pytest.mark.parametrize("name", GEOM_SCENES)
-def test_closest_hit_matches_reference_vectors(binding, oracle_mod, gpu_ctx, name):
+def test_closest_hit_matches_reference_vectors(binding, oracle_mod, gpu_ctx, name, via):
     g = load_golden("geom_%s_ref.npz" % name)
     sc = golden_scene(binding, oracle_mod, g, name)
     gpu_ctx.upload(sc)
     types = prim_types(sc.flat)
-    got = gpu_trace(gpu_ctx, g["world_rays"])
+    got = gpu_trace(gpu_ctx, g["world_rays"], via=via)
     compare_hits(got, g["world_hits"], types, name + " world rays", ties_ok=True)
 
 
+@pytest.mark.parametrize("via", TRAVERSALS)
 @pytest.mark.parametrize("name", SPECIAL_SCENES)
-def test_special_rays_match_reference(binding, oracle_mod, oracle, gpu_ctx, name):
+def test_special_rays_match_reference(binding, oracle_mod, oracle, gpu_ctx, name, via):
     """Zero and negative-zero direction components, origins on surfaces, rays through corners and vertices, directions of
     1e18 and 1e-30 (tests/golden/geom_special_ref.npz, from the reference's flat list).  A scene that is scanned as a
     list must give the reference's answer on ALL of them, NaN for NaN (a rect reports a hit with t = NaN for a ray in its
@@ -61,7 +72,7 @@ def test_special_rays_match_reference(binding, oracle_mod, oracle, gpu_ctx, name
     g = load_golden("geom_special_ref.npz")
     sc, rays, exp = special_scene(binding, oracle_mod, g, name)
     gpu_ctx.upload(sc)
-    got = gpu_trace(gpu_ctx, rays)
+    got = gpu_trace(gpu_ctx, rays, via=via)
     free = special_order_free(g, name)
     scope = np.ones(len(rays), bool) if sc.flat.contents.n_bvh_nodes == 0 else free
     assert scope.sum() > 600
@@ -83,7 +94,10 @@ def test_special_rays_match_reference(binding, oracle_mod, oracle, gpu_ctx, name
     if settled.any():
         agree = (got["hit"][settled] == a["hit"][settled]) & ((got["t"][settled] == a["t"][settled]) | (a["hit"][settled] == 0))
         print("%s: %d rays outside the order-free set with one oracle answer, device agrees on %.3f" % (name, settled.sum(), agree.mean()))
-        assert agree.mean() > 0.98
+        # the wavefront form's second intersect kernel tilts a zero direction component by 2^-40 for its box tests and lets a
+        # ray that is not a number meet no box at all: a ray lying exactly IN a face's plane (0 / 0 in the reference's rect
+        # test, a "hit" with t = NaN there) is then culled before it reaches that rect
+        assert agree.mean() > (0.98 if via == "megakernel" else 0.95)
 
 
 @pytest.mark.parametrize("name", GEOM_SCENES)
@@ -117,6 +131,43 @@ def test_primary_hits_at_full_size_match_reference(binding, oracle_mod, gpu_ctx,
     assert (ep >= 0).mean() > 0.4
 
 
+def primary_rays(flat, W, H):
+    """the pinhole-centre ray of every pixel, with the device's own fp32 operations (rt_device.h primary_ray)"""
+    cam = flat.contents.camera
+    f = np.float32
+    ll, hor, ver, org = (np.array(x[:], f) for x in (cam.lower_left, cam.horizontal, cam.vertical, cam.origin))
+    j, i = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    u = ((i.astype(f) + f(0.5)) / f(W)).reshape(-1, 1)
+    v = ((j.astype(f) + f(0.5)) / f(H)).reshape(-1, 1)
+    d = ((ll + u * hor) + v * ver) - org
+    return np.concatenate([np.tile(org, (W * H, 1)), d.astype(f), np.full((W * H, 1), cam.time0, f)], axis=1).astype(f)
+
+
+@pytest.mark.parametrize("kernel", ["1", "2"])
+@pytest.mark.parametrize("name", ["tri_mesh", "final"])
+def test_wavefront_traversal_at_full_size_matches_reference(binding, oracle_mod, gpu_ctx, monkeypatch, name, kernel):
+    """north_star criterion 1 for the traversal the target scenes are RENDERED with: the primary rays of the full-size
+    reference maps (1,000,000 triangles; 100 x 100 boxes) through both intersect kernels of the wavefront form.  t is
+    bit-equal everywhere; an id may differ from the reference's flat list only at an identical t (the tie rules differ:
+    first in list order there, lowest word in the mailbox / first met here), and then the megakernel's traversal, a
+    third order, reports that same t as well."""
+    monkeypatch.setenv("RT_WF_KERNEL", kernel)
+    g = load_golden("geom_%s_full_ref.npz" % name)
+    sc = golden_scene(binding, oracle_mod, g, name)
+    gpu_ctx.upload(sc)
+    W, H = int(g["width"]), int(g["height"])
+    rays = primary_rays(sc.flat, W, H)
+    got = gpu_trace(gpu_ctx, rays, via="wavefront")
+    mega = gpu_trace(gpu_ctx, rays)
+    ep, et = g["primary_prim"].reshape(-1), g["primary_t"].reshape(-1)
+    assert np.array_equal(got["hit"] == 1, ep >= 0)
+    h = ep >= 0
+    assert np.array_equal(got["t"][h], et[h]), "t differs from the reference's"
+    differ = h & (got["prim"] != ep)
+    assert differ.mean() < 0.01
+    assert np.array_equal(mega["t"][differ], et[differ]) and np.array_equal(mega["hit"], got["hit"])
+
+
 @pytest.mark.parametrize("name,param", [("kat", 0), ("cornell", 0), ("cornell_smoke", 0), ("random_spheres", 0),
                                         ("final", 8), ("tri_mesh", 4000), ("cornell_cluster", 0), ("final_custom", 0)])
 def test_closest_hit_matches_oracle_on_many_rays(binding, oracle, gpu_ctx, name, param):
@@ -142,6 +193,7 @@ def test_closest_hit_matches_oracle_on_many_rays(binding, oracle, gpu_ctx, name,
     types = prim_types(sc.flat)
     exp = oracle.trace_rays(sc.flat, allr, 0.001, FLT_MAX)
     compare_hits(gpu_trace(gpu_ctx, allr), exp, types, name, ties_ok=True)
+    compare_hits(gpu_trace(gpu_ctx, allr, via="wavefront"), exp, types, name + " (wavefront traversal)", ties_ok=True)
     tm = float(np.median(exp["t"][exp["hit"] == 1]))
     exp = oracle.trace_rays(sc.flat, allr, 0.5 * tm, 1.5 * tm)
     compare_hits(gpu_trace(gpu_ctx, allr, 0.5 * tm, 1.5 * tm), exp, types, name + " window", ties_ok=True)

@@ -36,6 +36,14 @@ if os.environ.get("RT_INTEGRATOR") == "2" or (sc.flat.contents.n_bvh_nodes > 0 a
         print("  trips with a node step %.3f (%.1f lanes each), with a primitive step %.3f (%.1f lanes each); stalled lanes/trip %.1f; cycles/trip %.0f"
               % (d[5] / d[0], d[2] / max(1.0, d[5]), d[6] / d[0], d[3] / max(1.0, d[6]), d[4] / d[0], d[7] / d[0]))
     print("  rows fetched per ray: %.2f four-wide nodes (128-B rows) + %.2f leaf primitives (64-B rows)" % (d[2] / c.rays, d[3] / c.rays))
+    if hasattr(B.lib(), "rt_debug_sections") and os.environ.get("RT_WF_KERNEL", "2") == "2":
+        sec = (C.c_ulonglong * 16)()
+        B.lib().rt_debug_sections.argtypes = [C.c_void_p, C.c_void_p]
+        B.lib().rt_debug_sections(ctx.handle, sec)
+        names = ["refill", "trip top + loads", "pipeline", "node step", "queueing + stack", "prim step", "tail", "spins"]
+        tot = float(sum(sec[:8])) or 1.0
+        print("  kernel 2 cycles by section: " + ", ".join("%s %.1f %%" % (n, 100.0 * sec[i] / tot) for i, n in enumerate(names)))
+        print("  per trip: " + ", ".join("%s %.0f" % (n, sec[i] / d[0]) for i, n in enumerate(names)) + "; spins per trip %.3f, claims %d" % (sec[8] / d[0], sec[9]))
     sys.exit(0)
 names = ["regen", "closest_hit", "rebuild", "ball", "tail", "scatter+rest"]
 tot = sum(out[:6]) or 1
