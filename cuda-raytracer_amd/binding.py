@@ -81,7 +81,7 @@ EXPORTS = [
     "rt_last_error", "rt_scene_create_builtin", "rt_scene_from_flat", "rt_scene_flat",
     "rt_scene_default_background", "rt_scene_destroy", "rt_ctx_create", "rt_ctx_destroy",
     "rt_scene_upload", "rt_trace_rays", "rt_trace_rays_wavefront", "rt_trace_primary", "rt_shade_rays", "rt_texture_values", "rt_render_accumulate", "rt_render_accumulate_window", "rt_render_accumulate_noalloc", "rt_resolve",
-    "rt_ctx_set_integrator", "rt_reduce_accum", "rt_reduce_scatter_rows", "rt_synchronize", "rt_get_counters", "rt_reset_counters", "rt_quantise_rgb8", "rt_write_ppm", "rt_write_png", "rt_read_ppm", "rt_free_pixels", "rt_flat_features", "rt_flat_program", "rt_flat_program_split", "rt_flat_bvh_stats", "rt_flat_bvh4_single_refs",
+    "rt_ctx_set_integrator", "rt_reduce_accum", "rt_reduce_scatter_rows", "rt_synchronize", "rt_get_counters", "rt_reset_counters", "rt_quantise_rgb8", "rt_write_ppm", "rt_write_png", "rt_read_ppm", "rt_free_pixels", "rt_flat_features", "rt_flat_program", "rt_flat_program_split", "rt_flat_bvh_stats", "rt_flat_bvh4_single_refs", "rt_flat_bvh8_check",
 ]
 
 
@@ -133,6 +133,7 @@ def load_library(path=LIB_PATH):
     lib.rt_flat_program_split.argtypes = [C.POINTER(RtFlatScene), vp, i32, vp, i32, C.POINTER(C.c_int)]
     lib.rt_flat_bvh_stats.argtypes = [C.POINTER(RtFlatScene)] + [C.POINTER(C.c_int)] * 4
     lib.rt_flat_bvh4_single_refs.argtypes = [C.POINTER(RtFlatScene)]
+    lib.rt_flat_bvh8_check.argtypes = [C.POINTER(RtFlatScene), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]
     return lib
 
 

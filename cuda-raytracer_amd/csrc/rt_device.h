@@ -41,6 +41,8 @@ struct DScene {
     const DNode*       __restrict__ nodes;   /* 64-byte two-box nodes (rt_host.h) */
     const DNode4*      __restrict__ nodes4;  /* 128-byte four-box nodes of the same trees (wavefront) */
     const DObj*        __restrict__ leafs;   /* BVH leaf table: first 64 bytes of each row are read */
+    const DNode8*      __restrict__ nodes8;  /* 80-byte eight-wide quantised nodes of the same trees (rt_wavefront8.h) */
+    const DLeaf*       __restrict__ leafs8;  /* their leaf table: 16 rows of 64 bytes per node */
     const DProg*       __restrict__ prog;    /* the world list as 32-byte scan records (rt_host.h) */
     int32_t world;
     int32_t n_media;

@@ -8,8 +8,17 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <vector>
 #include "../../include/rt_api.h"
+
+/* what a node step and a primitive test cost against each other when rt_pack_bvh8 chooses its children */
+#ifndef RT_BVH8_C_NODE
+#define RT_BVH8_C_NODE 1.0f
+#endif
+#ifndef RT_BVH8_C_PRIM
+#define RT_BVH8_C_PRIM 0.3f
+#endif
 
 static thread_local std::string g_err;
 void rt_set_error(const std::string& msg) { g_err = msg; }
@@ -305,6 +314,216 @@ void rt_pack_bvh4(const rt_flat_scene* s, std::vector<DObj>& objs, std::vector<D
     if (depth) *depth = deepest;
 }
 
+bool rt_pack_bvh8(const rt_flat_scene* s, std::vector<DObj>& objs, std::vector<DNode8>& nodes8, std::vector<DLeaf>& leafs8, int* depth, float* box_abs)
+{
+    nodes8.clear();
+    leafs8.clear();
+    int deepest = 0;
+    float amax = 0.f;
+    struct Box { float lo[3], hi[3]; };
+    auto node_box = [&](uint32_t ni) { Box b; const rt_bvh_node& n = s->bvh_nodes[ni]; for (int a = 0; a < 3; ++a) { b.lo[a] = n.bmin[a]; b.hi[a] = n.bmax[a]; } return b; };
+    auto area = [&](uint32_t ni) {
+        const rt_bvh_node& n = s->bvh_nodes[ni];
+        float e0 = n.bmax[0] - n.bmin[0], e1 = n.bmax[1] - n.bmin[1], e2 = n.bmax[2] - n.bmin[2];
+        return e0 * e1 + e1 * e2 + e2 * e0;
+    };
+    /* an item behind its own padded box (as rt_pack_bvh4 opens leaves), if its bounds can be trusted */
+    auto item_box = [&](int32_t item, const rt_bvh_node& leaf, Box& b) {
+        const rt_object& o = s->objects[s->bvh_items[item]];
+        for (int a = 0; a < 3; ++a) {
+            if (!(std::isfinite(o.bmin[a]) && std::isfinite(o.bmax[a]) && o.bmin[a] <= o.bmax[a])) return false;
+            const float m = std::max(std::fabs(o.bmin[a]), std::fabs(o.bmax[a])), slack = 4e-5f * m + 4e-4f;
+            if (o.bmin[a] < leaf.bmin[a] - slack || o.bmax[a] > leaf.bmax[a] + slack) return false;
+            float pad = 1e-5f * m + 1e-6f;
+            if (o.bmax[a] - o.bmin[a] < 2e-4f) pad += 1e-4f;
+            b.lo[a] = o.bmin[a] - pad; b.hi[a] = o.bmax[a] + pad;
+        }
+        return true;
+    };
+    /* Which binary nodes become the children of an eight-wide node is chosen to minimise the surface-area cost of the
+     * whole wide tree (Ylitie, Karras, Laine 2017, section 3.1): cost[n][i-1] = the cheapest way to hand the subtree of
+     * binary node n to its ancestor as at most i children, where a child is a leaf slot (one item behind its own box, or
+     * a binary leaf of two behind the leaf's box) or an eight-wide node (its box's area * c_node + the cost of its own
+     * eight).  pick[n][i-1] = how many of the i go to the left child (0: use the answer for i - 1; for a leaf of two,
+     * 1: open it into two slots).  A greedy top-down collapse leaves the bottom nodes of a balanced tree a third full. */
+    const float c_node = RT_BVH8_C_NODE, c_prim = RT_BVH8_C_PRIM;
+    struct Dp { float cost[8]; uint8_t pick[8]; };
+    std::vector<Dp> dp((size_t)s->n_bvh_nodes);
+    auto box_area = [](const Box& b) { const float e0 = b.hi[0] - b.lo[0], e1 = b.hi[1] - b.lo[1], e2 = b.hi[2] - b.lo[2]; return e0 * e1 + e1 * e2 + e2 * e0; };
+    auto solve = [&](uint32_t root) -> bool {
+        std::vector<std::pair<uint32_t, int>> st{{root, 0}};
+        while (!st.empty()) {
+            const uint32_t ni = st.back().first;
+            const rt_bvh_node& n = s->bvh_nodes[ni];
+            Dp& d = dp[ni];
+            if (n.count) {
+                st.pop_back();
+                if (n.count > 2) return false;
+                Box b0, b1;
+                for (int i = 0; i < 8; ++i) { d.cost[i] = area(ni) * (float)n.count * c_prim; d.pick[i] = 0; }
+                if (n.count == 1 && item_box((int32_t)n.left_first, n, b0)) for (int i = 0; i < 8; ++i) d.cost[i] = box_area(b0) * c_prim;
+                if (n.count == 2 && item_box((int32_t)n.left_first, n, b0) && item_box((int32_t)n.left_first + 1, n, b1)) {
+                    const float open = (box_area(b0) + box_area(b1)) * c_prim;
+                    if (open < d.cost[0]) for (int i = 1; i < 8; ++i) { d.cost[i] = open; d.pick[i] = 1; }
+                }
+                continue;
+            }
+            if (st.back().second == 0) { st.back().second = 1; st.push_back({n.left_first, 0}); st.push_back({n.left_first + 1, 0}); continue; }
+            st.pop_back();
+            const Dp& l = dp[n.left_first];
+            const Dp& r = dp[n.left_first + 1];
+            auto distribute = [&](int j, uint8_t& k_best) {            /* j children in all, k of them from the left */
+                float best = 3.0e38f;
+                for (int k = 1; k < j; ++k) {
+                    if (k > 7 || j - k > 7) continue;
+                    const float c = l.cost[k - 1] + r.cost[j - k - 1];
+                    if (c < best) { best = c; k_best = (uint8_t)k; }
+                }
+                return best;
+            };
+            d.cost[0] = distribute(8, d.pick[0]) + area(ni) * c_node;
+            for (int i = 2; i <= 8; ++i) {
+                uint8_t k = 0;
+                const float c = distribute(i, k);
+                if (c < d.cost[i - 2]) { d.cost[i - 1] = c; d.pick[i - 1] = k; } else { d.cost[i - 1] = d.cost[i - 2]; d.pick[i - 1] = 0; }
+            }
+        }
+        return true;
+    };
+    struct Cand { uint32_t node; int32_t item; Box box; };      /* item >= 0: ONE item of the leaf `node`, behind its own box */
+    struct Todo { uint32_t abi; uint32_t node8; int level; };
+    /* the children the table chose for binary node ni given i slots; own = ni is the eight-wide node being filled */
+    auto gather = [&](auto& self, uint32_t ni, int i, bool own, std::vector<Cand>& out) -> void {
+        const rt_bvh_node& n = s->bvh_nodes[ni];
+        const Dp& d = dp[ni];
+        if (!own) {
+            while (i > 1 && d.pick[i - 1] == 0) --i;
+            if (i == 1) { out.push_back({ni, -1, node_box(ni)}); return; }
+            if (n.count) {            /* a leaf of two, opened */
+                Box b0, b1;
+                item_box((int32_t)n.left_first, n, b0); item_box((int32_t)n.left_first + 1, n, b1);
+                out.push_back({ni, (int32_t)n.left_first, b0});
+                out.push_back({ni, (int32_t)n.left_first + 1, b1});
+                return;
+            }
+        }
+        const int k = own ? d.pick[0] : d.pick[i - 1];
+        self(self, n.left_first, k, false, out);
+        self(self, n.left_first + 1, (own ? 8 : i) - k, false, out);
+    };
+    for (int gi = 0; gi < s->n_objects; ++gi) {
+        const rt_object& g = s->objects[gi];
+        if (g.type != RT_OBJ_GROUP || g.bvh_root < 0) continue;
+        if (!solve((uint32_t)g.bvh_root)) return false;
+        std::vector<Todo> todo;
+        objs[(size_t)gi].pad[1] = (int32_t)nodes8.size();
+        nodes8.push_back(DNode8());
+        todo.push_back({(uint32_t)g.bvh_root, (uint32_t)nodes8.size() - 1u, 1});
+        while (!todo.empty()) {
+            const Todo e = todo.back();
+            todo.pop_back();
+            if (e.level > deepest) deepest = e.level;
+            const rt_bvh_node& n = s->bvh_nodes[e.abi];
+            std::vector<Cand> cands;
+            if (n.count) {            /* a tree that is one leaf */
+                Box b0, b1;
+                if (n.count == 2 && item_box((int32_t)n.left_first, n, b0) && item_box((int32_t)n.left_first + 1, n, b1)) {
+                    cands.push_back({e.abi, (int32_t)n.left_first, b0});
+                    cands.push_back({e.abi, (int32_t)n.left_first + 1, b1});
+                } else cands.push_back({e.abi, -1, node_box(e.abi)});
+            } else gather(gather, e.abi, 8, true, cands);
+            /* the node's own box = the union of what it holds; slots by octant: the child whose centre lies furthest
+             * towards an octant's corner takes that slot, greedily */
+            Box nb = cands[0].box;
+            for (const Cand& c : cands) for (int a = 0; a < 3; ++a) { nb.lo[a] = std::min(nb.lo[a], c.box.lo[a]); nb.hi[a] = std::max(nb.hi[a], c.box.hi[a]); }
+            int slot_of[8], cand_at[8];
+            for (int k = 0; k < 8; ++k) { slot_of[k] = -1; cand_at[k] = -1; }
+            for (size_t round = 0; round < cands.size(); ++round) {
+                double best = -1e300;
+                int bc = -1, bs = -1;
+                for (size_t k = 0; k < cands.size(); ++k) {
+                    if (slot_of[k] >= 0) continue;
+                    for (int sl = 0; sl < 8; ++sl) {
+                        if (cand_at[sl] >= 0) continue;
+                        double score = 0.0;
+                        for (int a = 0; a < 3; ++a) {
+                            const double rel = 0.5 * ((double)cands[k].box.lo[a] + cands[k].box.hi[a]) - 0.5 * ((double)nb.lo[a] + nb.hi[a]);
+                            score += ((sl >> a) & 1) ? rel : -rel;
+                        }
+                        if (score > best) { best = score; bc = (int)k; bs = sl; }
+                    }
+                }
+                slot_of[bc] = bs; cand_at[bs] = bc;
+            }
+            /* interior children get consecutive nodes in slot order */
+            uint32_t imask = 0, lmask = 0, l2mask = 0;
+            const uint32_t child_base = (uint32_t)nodes8.size();
+            for (int sl = 0; sl < 8; ++sl) {
+                if (cand_at[sl] < 0) continue;
+                const Cand& c = cands[(size_t)cand_at[sl]];
+                if (c.item < 0 && s->bvh_nodes[c.node].count == 0) {
+                    imask |= 1u << sl;
+                    nodes8.push_back(DNode8());
+                    todo.push_back({c.node, (uint32_t)nodes8.size() - 1u, e.level + 1});
+                } else {
+                    lmask |= 1u << sl;
+                    if (c.item < 0 && s->bvh_nodes[c.node].count == 2) l2mask |= 1u << sl;
+                }
+            }
+            DNode8& d = nodes8[(size_t)e.node8];          /* taken after the push_backs: they may move the vector */
+            std::memset(&d, 0, sizeof d);
+            uint32_t ebytes = 0;
+            double scale[3];
+            for (int a = 0; a < 3; ++a) {
+                d.p[a] = nb.lo[a];
+                amax = std::max(amax, std::max(std::fabs(nb.lo[a]), std::fabs(nb.hi[a])));
+                const double ext = (double)nb.hi[a] - (double)nb.lo[a];
+                int ex = ext > 0.0 ? (int)std::ceil(std::log2(ext / 255.0)) : -100;
+                ex = std::max(-100, std::min(100, ex));
+                while (std::ldexp(255.0, ex) < ext) ++ex;
+                scale[a] = std::ldexp(1.0, ex);
+                ebytes |= (uint32_t)(ex + 127) << (8 * a);
+            }
+            d.e_imask = ebytes | (imask << 24);
+            d.child_base = child_base;
+            d.leaf_masks = lmask | (l2mask << 8);
+            for (int sl = 0; sl < 8; ++sl) {
+                for (int a = 0; a < 3; ++a) {
+                    uint32_t ql = 255u, qh = 0u;            /* an empty slot: inverted */
+                    if (cand_at[sl] >= 0) {
+                        const Box& b = cands[(size_t)cand_at[sl]].box;
+                        const double lo = std::floor(((double)b.lo[a] - (double)d.p[a]) / scale[a]), hi = std::ceil(((double)b.hi[a] - (double)d.p[a]) / scale[a]);
+                        ql = (uint32_t)std::max(0.0, std::min(255.0, lo));
+                        qh = (uint32_t)std::max(0.0, std::min(255.0, hi));
+                    }
+                    d.qlo[a][sl >> 2] |= ql << (8 * (sl & 3));
+                    d.qhi[a][sl >> 2] |= qh << (8 * (sl & 3));
+                }
+            }
+            /* the items of the leaf children: rows 16 * node + slot and 16 * node + 8 + slot */
+            if (lmask) {
+                const size_t base = 16 * (size_t)e.node8;
+                if (leafs8.size() < base + 16) leafs8.resize(base + 16);
+                for (int sl = 0; sl < 8; ++sl) {
+                    if (!((lmask >> sl) & 1u)) continue;
+                    const Cand& c = cands[(size_t)cand_at[sl]];
+                    const int32_t first = c.item >= 0 ? c.item : (int32_t)s->bvh_nodes[c.node].left_first;
+                    const int cnt = c.item >= 0 ? 1 : (int)s->bvh_nodes[c.node].count;
+                    for (int j = 0; j < cnt; ++j) {
+                        DObj row = objs[(size_t)s->bvh_items[first + j]];
+                        row.prim_id = s->bvh_items[first + j];          /* the object's index, as in the other leaf table */
+                        std::memcpy(&leafs8[base + 8 * (size_t)j + (size_t)sl], &row, sizeof(DLeaf));
+                    }
+                }
+            }
+        }
+    }
+    if (leafs8.size() < 16 * nodes8.size()) leafs8.resize(16 * nodes8.size());
+    if (depth) *depth = deepest;
+    if (box_abs) *box_abs = amax;
+    return true;
+}
+
 void rt_pack_program(const rt_flat_scene* s, std::vector<DProg>& prog, std::vector<DProg>* prog_nobvh, std::vector<int>* bvh_groups)
 {
     prog.clear();
@@ -465,6 +684,76 @@ extern "C" int rt_flat_bvh4_single_refs(const rt_flat_scene* flat)
     int n = 0;
     for (const DNode4& d : n4) for (int k = 0; k < 4; ++k) if (d.ref[k] < 0 && d.ref[k] != RT_REF_NONE && ((uint32_t)(~d.ref[k]) & 15u) == 0u) ++n;
     return n;
+}
+
+/* The 8-wide quantised trees of a scene, checked on the host: every BVH item sits in exactly one row of the leaf table,
+ * every dequantised child box contains the box it was made from (interior child: the union of ITS children's dequantised
+ * boxes; leaf child: its items' own bounds), every node is reached exactly once.  Returns the number of nodes, or a
+ * negative rt_status (RT_ERR_UNSUPPORTED: a leaf of more than two items).  depth8 / rows_used / max_q_slack are optional. */
+extern "C" int rt_flat_bvh8_check(const rt_flat_scene* flat, int* depth8, int* rows_used, float* max_q_slack)
+{
+    std::string why;
+    if (!flat || !rt_validate_scene(flat, why, nullptr)) { rt_set_error("rt_flat_bvh8_check: invalid scene: " + why); return RT_ERR_ARG; }
+    std::vector<DObj> objs((size_t)flat->n_objects);
+    rt_pack_objects(flat, objs.data());
+    std::vector<DNode8> n8;
+    std::vector<DLeaf> l8;
+    int d8 = 0;
+    float amax = 0.f;
+    if (!rt_pack_bvh8(flat, objs, n8, l8, &d8, &amax)) { rt_set_error("rt_flat_bvh8_check: a leaf holds more than two items"); return RT_ERR_UNSUPPORTED; }
+    std::vector<int> item_seen((size_t)flat->n_objects, 0), node_seen(n8.size(), 0);
+    int rows = 0;
+    double slack = 0.0;
+    struct B { double lo[3], hi[3]; };
+    auto child_box = [&](const DNode8& d, int sl) {
+        B b;
+        for (int a = 0; a < 3; ++a) {
+            const double sc = std::ldexp(1.0, (int)((d.e_imask >> (8 * a)) & 0xffu) - 127);
+            b.lo[a] = (double)d.p[a] + sc * (double)((d.qlo[a][sl >> 2] >> (8 * (sl & 3))) & 0xffu);
+            b.hi[a] = (double)d.p[a] + sc * (double)((d.qhi[a][sl >> 2] >> (8 * (sl & 3))) & 0xffu);
+        }
+        return b;
+    };
+    /* every item must lie inside its own slot's box AND inside the slot box of every ancestor it is reached through */
+    bool ok = true;
+    std::vector<B> above;
+    std::function<void(uint32_t)> walk = [&](uint32_t ni) {
+        if (ni >= n8.size() || node_seen[ni]++) { ok = false; return; }
+        const DNode8& d = n8[ni];
+        const uint32_t imask = d.e_imask >> 24, lmask = d.leaf_masks & 0xffu, l2 = (d.leaf_masks >> 8) & 0xffu;
+        if (imask & lmask) ok = false;
+        int below = 0;
+        for (int sl = 0; sl < 8; ++sl) {
+            const B b = child_box(d, sl);
+            if ((imask >> sl) & 1u) {
+                above.push_back(b);
+                walk(d.child_base + (uint32_t)below++);
+                above.pop_back();
+            } else if ((lmask >> sl) & 1u) {
+                for (int j = 0; j < (((l2 >> sl) & 1u) ? 2 : 1); ++j) {
+                    const DLeaf& row = l8[16 * (size_t)ni + 8 * (size_t)j + (size_t)sl];
+                    const int oi = (int)row.w[2];
+                    if (oi < 0 || oi >= flat->n_objects || item_seen[(size_t)oi]++) { ok = false; continue; }
+                    ++rows;
+                    const rt_object& o = flat->objects[oi];
+                    for (int a = 0; a < 3; ++a) {
+                        if ((double)o.bmin[a] < b.lo[a] || (double)o.bmax[a] > b.hi[a]) ok = false;
+                        for (const B& up : above) if ((double)o.bmin[a] < up.lo[a] || (double)o.bmax[a] > up.hi[a]) ok = false;
+                        slack = std::max(slack, std::max((double)o.bmin[a] - b.lo[a], b.hi[a] - (double)o.bmax[a]));
+                    }
+                }
+            }
+        }
+    };
+    for (int gi = 0; gi < flat->n_objects; ++gi)
+        if (flat->objects[gi].type == RT_OBJ_GROUP && flat->objects[gi].bvh_root >= 0) (void)walk((uint32_t)objs[(size_t)gi].pad[1]);
+    for (size_t i = 0; i < n8.size(); ++i) if (node_seen[i] != 1) ok = false;
+    for (int i = 0; i < flat->n_bvh_items; ++i) if (item_seen[(size_t)flat->bvh_items[i]] != 1) ok = false;
+    if (!ok || rows != flat->n_bvh_items) { rt_set_error("rt_flat_bvh8_check: the 8-wide trees do not hold every item once behind boxes that contain it"); return RT_ERR_UNSUPPORTED; }
+    if (depth8) *depth8 = d8;
+    if (rows_used) *rows_used = rows;
+    if (max_q_slack) *max_q_slack = (float)slack;
+    return (int)n8.size();
 }
 
 extern "C" int rt_flat_bvh_stats(const rt_flat_scene* flat, int* nodes2, int* depth2, int* nodes4, int* depth4)

@@ -80,6 +80,26 @@ struct alignas(16) DNode4 {
     int32_t pad[4];
 };
 
+/* 8-wide node with quantised child boxes for the third intersect kernel (rt_wavefront8.h), 80 bytes = five 16-byte lane
+ * loads (the four-wide node above needs seven, and a ray visits about 1.6 times as many of those).  A child box is
+ * p + q * 2^e per axis with 8-bit q, rounded outwards on the host.  Slot s holds the child that lies towards the octant s
+ * of the node (bit k of s set = the upper side along axis k), so that a ray whose direction signs form the octant o
+ * (bit k set = negative) meets the slots in roughly front-to-back order when it takes them by ascending s ^ o: no sort.
+ * Interior children are the nodes child_base + (number of interior slots below s); the items of leaf children are rows
+ * of a leaf table laid out by NODE: row 16 * node + s is the first item of slot s, row 16 * node + 8 + s its second
+ * (leaves of one or two items, which is what the host's builder makes; rows of absent items are never read). */
+struct alignas(16) DNode8 {
+    float    p[3];
+    uint32_t e_imask;      /* exponent bytes e0 | e1 << 8 | e2 << 16 (biased by 127, i.e. the float's own exponent field) | interior mask << 24 */
+    uint32_t child_base;
+    uint32_t leaf_masks;   /* slots that are leaves | slots whose leaf has a second item << 8 */
+    uint32_t pad[2];
+    uint32_t qlo[3][2];    /* per axis: q of the lower planes of slots 0..3, 4..7, one byte each */
+    uint32_t qhi[3][2];
+};
+/* one row of that leaf table: the first 64 bytes of the object's DObj (head, material, object index, 13 parameters) */
+struct alignas(16) DLeaf { uint32_t w[16]; };
+
 #define RT_REF_NONE ((int32_t)0x80000000)
 #define RT_MAX_LEAF 16
 #define RT_MAX_STACK 64
@@ -105,6 +125,12 @@ bool rt_pack_bvh(const rt_flat_scene* s, std::vector<DObj>& objs, std::vector<DN
 /* the same trees collapsed to 4-wide nodes; each BVH group's root reference goes to DObj::pad[0].
  * depth receives the deepest chain of DNode4s (a traversal needs at most 3 stack entries per level). */
 void rt_pack_bvh4(const rt_flat_scene* s, std::vector<DObj>& objs, std::vector<DNode4>& nodes4, int* depth);
+
+/* the same trees collapsed to 8-wide quantised nodes + their leaf table (16 rows per node); each BVH group's root node
+ * goes to DObj::pad[1] (always a node, even for a tree that is one leaf).  Returns false when a leaf holds more than two
+ * items (a caller's own tree): such scenes keep the four-wide kernels.  depth = the deepest chain of nodes, box_abs = the
+ * largest absolute coordinate of any box (the traversal's rounding allowance is scaled by it). */
+bool rt_pack_bvh8(const rt_flat_scene* s, std::vector<DObj>& objs, std::vector<DNode8>& nodes8, std::vector<DLeaf>& leafs8, int* depth, float* box_abs);
 
 /* the world list -> program records (terminated by one RT_P_END record) */
 /* prog: the world list as scan records.  For the wavefront integrator, which runs the list's plain records when

@@ -25,6 +25,7 @@
 #include "rt_host.h"
 #include "rt_wavefront.h"
 #include "rt_wavefront2.h"
+#include "rt_wavefront8.h"
 #include "rt_reduce.h"
 
 /* feature sets the render kernel is compiled for (rt_host.h RT_F_*); a scene runs on the first one
@@ -435,9 +436,12 @@ struct rt_ctx {
     hipEvent_t wf_ev[WF_MAX_POOLS + 1] = {};
     int stack_depth = 0;      /* LDS stack entries per lane the uploaded BVHs need */
     int stack4 = 1;           /* entries a traversal of the 4-wide trees can need (3 per level) */
+    int depth8 = 0;           /* deepest chain of 8-wide nodes; 0 = the scene has no 8-wide trees (a leaf of more than two items) */
+    size_t n_nodes8 = 0;
+    float box_abs = 0.f;
     DScene ds;
     void* d_objs = nullptr;  void* d_ops = nullptr;   void* d_mats = nullptr; void* d_texs = nullptr;
-    void* d_image = nullptr; void* d_nodes = nullptr; void* d_leafs = nullptr; void* d_prog = nullptr; void* d_nodes4 = nullptr;
+    void* d_image = nullptr; void* d_nodes = nullptr; void* d_leafs = nullptr; void* d_prog = nullptr; void* d_nodes4 = nullptr; void* d_nodes8 = nullptr; void* d_leafs8 = nullptr;
     float* d_partial = nullptr; size_t partial_floats = 0;    /* per-group frames of the megakernel's sample groups */
     float* noalloc_scratch = nullptr;  /* this device's copy of rt_noalloc_scratch, looked up at rt_ctx_create */
     void* d_prog_wf = nullptr; void* d_wf_groups = nullptr;   /* the world list in the wavefront integrator's form */
@@ -451,7 +455,7 @@ struct rt_ctx {
 
 static void free_scene(rt_ctx* c)
 {
-    void** ptrs[] = {&c->d_objs, &c->d_ops, &c->d_mats, &c->d_texs, &c->d_image, &c->d_nodes, &c->d_leafs, &c->d_prog, &c->d_nodes4,
+    void** ptrs[] = {&c->d_objs, &c->d_ops, &c->d_mats, &c->d_texs, &c->d_image, &c->d_nodes, &c->d_leafs, &c->d_prog, &c->d_nodes4, &c->d_nodes8, &c->d_leafs8,
                      &c->d_prog_wf, &c->d_wf_groups};
     for (void** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
     c->have_scene = false;
@@ -545,6 +549,11 @@ extern "C" int rt_scene_upload(rt_ctx* c, const rt_flat_scene* s)
     std::vector<DNode4> nodes4;
     int depth4 = 0;
     rt_pack_bvh4(s, objs, nodes4, &depth4);
+    std::vector<DNode8> nodes8;
+    std::vector<DLeaf> leafs8;
+    int depth8 = 0;
+    float box_abs = 0.f;
+    if (!rt_pack_bvh8(s, objs, nodes8, leafs8, &depth8, &box_abs)) { nodes8.clear(); leafs8.clear(); depth8 = 0; }
     std::vector<DProg> prog, prog_wf;
     std::vector<int> wf_groups;
     rt_pack_program(s, prog, &prog_wf, &wf_groups);
@@ -578,6 +587,8 @@ extern "C" int rt_scene_upload(rt_ctx* c, const rt_flat_scene* s)
     if ((rc = upload(c, &c->d_leafs, leafs.data(), leafs.size()))) return rc;
     if ((rc = upload(c, &c->d_prog, prog.data(), prog.size()))) return rc;
     if ((rc = upload(c, &c->d_nodes4, nodes4.data(), nodes4.size()))) return rc;
+    if ((rc = upload(c, &c->d_nodes8, nodes8.data(), nodes8.size()))) return rc;
+    if ((rc = upload(c, &c->d_leafs8, leafs8.data(), leafs8.size()))) return rc;
     if ((rc = upload(c, &c->d_prog_wf, prog_wf.data(), prog_wf.size()))) return rc;
     if ((rc = upload(c, &c->d_wf_groups, wf_groups.data(), wf_groups.size()))) return rc;
     c->n_wf_groups = (int)wf_groups.size();
@@ -592,6 +603,9 @@ extern "C" int rt_scene_upload(rt_ctx* c, const rt_flat_scene* s)
     c->ds.leafs = (const DObj*)c->d_leafs;
     c->ds.prog = (const DProg*)c->d_prog;
     c->ds.nodes4 = (const DNode4*)c->d_nodes4;
+    c->ds.nodes8 = (const DNode8*)c->d_nodes8;
+    c->ds.leafs8 = (const DLeaf*)c->d_leafs8;
+    c->depth8 = depth8; c->n_nodes8 = nodes8.size(); c->box_abs = box_abs;
     c->stack4 = 3 * depth4 + 1;
     c->features = rt_scene_features(s);
     c->ds.world = s->world;
@@ -776,8 +790,12 @@ static int wf_pick_kernel(const rt_ctx* c)
 {
     const bool fits2 = c->n_bvh_items < (1 << WF2_ITEM_BITS) && c->n_objects < (1 << WF2_OBJ_BITS) - 1 && c->n_wf_groups <= WF2_MAX_GROUPS;
     int kernel = WF_KERNEL_DEFAULT == 2 && fits2 ? 2 : 1;
-    if (const char* e = std::getenv("RT_WF_KERNEL")) { const int v = std::atoi(e); if (v == 1 || (v == 2 && fits2)) kernel = v; }
-    if (c->stack4 > wf2_lds_stack(V & ~RT_F_NOISE) + wf2_ovf(V & ~RT_F_NOISE)) kernel = 1;      /* a tree deeper than this variant's stack */
+    /* 3 = the eight-wide quantised trees (rt_wavefront8.h): needs them built (leaves of at most two items), their rows
+     * addressable in a queue entry and their depth inside its stack */
+    const bool fits8 = fits2 && c->depth8 > 0 && c->depth8 <= WF8_LDS_STACK + WF8_OVF_STACK && 16 * c->n_nodes8 < ((size_t)1 << WF2_ITEM_BITS);
+    if (WF_KERNEL_DEFAULT == 3 && fits8) kernel = 3;
+    if (const char* e = std::getenv("RT_WF_KERNEL")) { const int v = std::atoi(e); if (v == 1 || (v == 2 && fits2) || (v == 3 && fits8)) kernel = v; }
+    if (kernel == 2 && c->stack4 > wf2_lds_stack(V & ~RT_F_NOISE) + wf2_ovf(V & ~RT_F_NOISE)) kernel = 1;      /* a tree deeper than this variant's stack */
     if (!wf2_built(V)) kernel = 1;
     return kernel;
 }
@@ -835,8 +853,9 @@ static int wf_run_part(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t 
      * (11 plain records) 2.78 / 2.93 / 3.01 / 3.04 / 3.01 / 2.90; 1M triangles (1 record) 2.08 / 2.10 / 2.12 / 2.12 / 2.12 / 2.09 */
     W.refill_min = 40;
     const int kernel = wf_pick_kernel<V>(c);
-    if (kernel == 2) W.refill_min = 12;        /* handing over a staged ray is a few LDS reads */
+    if (kernel >= 2) W.refill_min = 12;        /* handing over a staged ray is a few LDS reads */
     W.bare = 0;
+    W.box_abs = c->box_abs;
     /* XCD-affine claims of the queue (rt_wavefront.h): with the queue in slot order they raise the intersect kernel's L2
      * hit rate on the 1M-triangle scene from 30 % to 56 % (L2 misses x 0.61) for +1 % in rate there and +-0 on the final
      * scene: the misses were one of three limits that sit close together.  RT_WF_AFFINE=0 turns them off. */
@@ -846,7 +865,8 @@ static int wf_run_part(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t 
     if (const char* e = std::getenv("RT_WF_REFILL")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) W.refill_min = v; }
     if (c->stack4 > WF_LDS_STACK + WF_OVF_STACK) { rt_set_error("wavefront integrator: BVH deeper than its traversal stack"); return RT_ERR_UNSUPPORTED; }
     const int lds_stack = kernel == 2 ? wf2_lds_stack(V & ~RT_F_NOISE) : WF_LDS_STACK;
-    const size_t lds = (size_t)(c->stack4 < lds_stack ? c->stack4 : lds_stack) * RT_BLOCK * sizeof(int);
+    const size_t lds = kernel == 3 ? (size_t)(c->depth8 < WF8_LDS_STACK ? c->depth8 : WF8_LDS_STACK) * RT_BLOCK * sizeof(uint2)
+                                   : (size_t)(c->stack4 < lds_stack ? c->stack4 : lds_stack) * RT_BLOCK * sizeof(int);
     /* Pools.  The slots are cut into three pools by sample stream and each pool runs its own intersect / logic loop
      * on a stream of its own, with a persistent intersect grid of a third of the size: while one pool's intersect
      * launch drains (its waves waiting for their last rays) or its logic kernel waits on memory, the other pools'
@@ -929,8 +949,11 @@ static int wf_run_part(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t 
                     const unsigned blocks = (P.known + RT_BLOCK - 1) / RT_BLOCK;
                     const unsigned iblocks = blocks < iblocks_max ? blocks : iblocks_max;
                     const unsigned lblocks = (P.known + WF_SPAN - 1) / WF_SPAN;
-                    if constexpr (wf2_built(V)) { if (kernel == 2) wf_intersect2_kernel<(V & ~RT_F_NOISE)><<<dim3(iblocks), RT_BLOCK, lds, P.st>>>(c->ds, P.W, P.cur, k0, k1, c->d_counters); }
-                    if (kernel != 2) wf_intersect_kernel<(V & ~RT_F_NOISE)><<<dim3(iblocks), RT_BLOCK, lds, P.st>>>(c->ds, P.W, P.cur, k0, k1, c->d_counters);   /* reads no texture */
+                    if constexpr (wf2_built(V)) {
+                        if (kernel == 2) wf_intersect2_kernel<(V & ~RT_F_NOISE)><<<dim3(iblocks), RT_BLOCK, lds, P.st>>>(c->ds, P.W, P.cur, k0, k1, c->d_counters);
+                        if (kernel == 3) wf_intersect8_kernel<(V & ~RT_F_NOISE)><<<dim3(iblocks), RT_BLOCK, lds, P.st>>>(c->ds, P.W, P.cur, k0, k1, c->d_counters);
+                    }
+                    if (kernel == 1) wf_intersect_kernel<(V & ~RT_F_NOISE)><<<dim3(iblocks), RT_BLOCK, lds, P.st>>>(c->ds, P.W, P.cur, k0, k1, c->d_counters);   /* reads no texture */
                     if (background == RT_BG_BLACK)
                         wf_logic_kernel<V, RT_BG_BLACK><<<dim3(lblocks), RT_BLOCK, 0, P.st>>>(c->ds, P.W, P.cur, w, h, s1, k0, k1, max_depth);
                     else
@@ -1012,12 +1035,14 @@ static int wf_trace(rt_ctx* c, int n, const float* rays, rt_hit_record* out)
     W.win_x0 = W.win_y0 = 0; W.win_w = W.frame_w = (uint32_t)n;
     W.prog = (const DProg*)c->d_prog_wf; W.groups = (const int*)c->d_wf_groups; W.n_groups = c->n_wf_groups;
     const int kernel = wf_pick_kernel<V>(c);
-    W.refill_min = kernel == 2 ? 12 : 40;
+    W.refill_min = kernel >= 2 ? 12 : 40;
     W.affine = 0;
     W.bare = 1;
+    W.box_abs = c->box_abs;
     if (c->stack4 > WF_LDS_STACK + WF_OVF_STACK) { rt_set_error("rt_trace_rays_wavefront: BVH deeper than the traversal stack"); return RT_ERR_UNSUPPORTED; }
     const int lds_stack = kernel == 2 ? wf2_lds_stack(V & ~RT_F_NOISE) : WF_LDS_STACK;
-    const size_t lds = (size_t)(c->stack4 < lds_stack ? c->stack4 : lds_stack) * RT_BLOCK * sizeof(int);
+    const size_t lds = kernel == 3 ? (size_t)(c->depth8 < WF8_LDS_STACK ? c->depth8 : WF8_LDS_STACK) * RT_BLOCK * sizeof(uint2)
+                                   : (size_t)(c->stack4 < lds_stack ? c->stack4 : lds_stack) * RT_BLOCK * sizeof(int);
     const unsigned blocks = (unsigned)((n + RT_BLOCK - 1) / RT_BLOCK);
     HIPCHK(hipMemsetAsync(W.count, 0, WF_POOL_COUNT_WORDS * sizeof(uint32_t), c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));                  /* the pinned word below may still be read by an earlier call's copy */
@@ -1025,8 +1050,11 @@ static int wf_trace(rt_ctx* c, int n, const float* rays, rt_hit_record* out)
     HIPCHK(hipMemcpyAsync(W.count, &c->wf_host_count[4 * WF_MAX_POOLS], sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     wf_trace_fill_kernel<<<dim3(blocks), RT_BLOCK, 0, c->stream>>>(W, n, rays);
     const unsigned iblocks = blocks < 2048u ? blocks : 2048u;
-    if constexpr (wf2_built(V)) { if (kernel == 2) wf_intersect2_kernel<(V & ~RT_F_NOISE)><<<dim3(iblocks), RT_BLOCK, lds, c->stream>>>(c->ds, W, 0, 0u, 0u, c->d_counters + 3); }
-    if (kernel != 2) wf_intersect_kernel<(V & ~RT_F_NOISE)><<<dim3(iblocks), RT_BLOCK, lds, c->stream>>>(c->ds, W, 0, 0u, 0u, c->d_counters + 3);
+    if constexpr (wf2_built(V)) {
+        if (kernel == 2) wf_intersect2_kernel<(V & ~RT_F_NOISE)><<<dim3(iblocks), RT_BLOCK, lds, c->stream>>>(c->ds, W, 0, 0u, 0u, c->d_counters + 3);
+        if (kernel == 3) wf_intersect8_kernel<(V & ~RT_F_NOISE)><<<dim3(iblocks), RT_BLOCK, lds, c->stream>>>(c->ds, W, 0, 0u, 0u, c->d_counters + 3);
+    }
+    if (kernel == 1) wf_intersect_kernel<(V & ~RT_F_NOISE)><<<dim3(iblocks), RT_BLOCK, lds, c->stream>>>(c->ds, W, 0, 0u, 0u, c->d_counters + 3);
     wf_trace_out_kernel<V><<<dim3(blocks), RT_BLOCK, 0, c->stream>>>(c->ds, W, n, rays, out);
     HIPCHK(hipGetLastError());
     return RT_OK;

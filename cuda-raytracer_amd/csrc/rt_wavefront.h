@@ -47,6 +47,7 @@ struct WfState {
     int refill_min;    /* idle lanes that make a refill (and its run over the plain records) worth while */
     int affine;        /* 1: a wave takes its chunks of the queue from the image band of its XCD first (below) */
     int bare;          /* 1: a bare closest-hit query (rt_trace_rays_wavefront): no RNG, media are ignored as in rt_trace_rays */
+    float box_abs;     /* the largest absolute coordinate of any BVH box (rt_wavefront8.h: scales the rounding allowance) */
 };
 
 /* slot -> pixel: stream k of window pixel p is slot k * n_pixels + p; returns the pixel's index in the FRAME,

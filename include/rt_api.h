@@ -200,6 +200,11 @@ int  rt_flat_program_split(const rt_flat_scene* flat, uint32_t* out_words, int c
                            int* n_groups);
 /* sizes of the device BVHs: two-box nodes, four-box nodes, traversal stack entries each needs */
 int  rt_flat_bvh_stats(const rt_flat_scene* flat, int* nodes2, int* depth2, int* nodes4, int* depth4);
+/* the 8-wide quantised trees the third intersect kernel walks, built and checked on the host: every BVH item in exactly
+ * one leaf-table row, every dequantised child box containing what it was made from, every node reached once.  Returns
+ * the node count, or a negative rt_status (RT_ERR_UNSUPPORTED: a leaf of more than two items; such scenes render with
+ * the four-wide kernels).  The out-parameters are optional. */
+int  rt_flat_bvh8_check(const rt_flat_scene* flat, int* depth8, int* rows_used, float* max_q_slack);
 /* how many child slots of the four-box nodes hold ONE item behind that item's own rt_object::bmin/bmax (a leaf is
  * opened that way only when its items' bounds are finite, ordered and inside the leaf's box; stale bounds in a
  * caller's table leave the leaf whole), or a negative rt_status */

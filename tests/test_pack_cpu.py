@@ -94,6 +94,22 @@ def test_device_bvhs(binding, name, param):
     assert 0 < d4.value <= d2.value and 3 * d4.value + 1 <= 64
 
 
+@pytest.mark.parametrize("name,param", [("kat", 0), ("random_spheres", 0), ("final", 12), ("tri_mesh", 5000), ("cornell_cluster", 0), ("bvh_boxes", 0)])
+def test_eight_wide_trees(binding, name, param):
+    """rt_flat_bvh8_check builds the eight-wide quantised trees (rt_pack_bvh8) and walks them: every BVH item sits in
+    exactly one leaf row, inside its slot's decoded box and inside the decoded slot box of every ancestor"""
+    sc = binding.Scene(name, 64, 64, param)
+    d8, rows, slack = C.c_int(), C.c_int(), C.c_float()
+    rc = binding.lib().rt_flat_bvh8_check(sc.flat, C.byref(d8), C.byref(rows), C.byref(slack))
+    assert rc > 0, binding.lib().rt_last_error()          # the number of eight-wide nodes
+    assert rows.value == sc.flat.contents.n_bvh_items
+    n2, d2, n4, d4 = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    assert binding.lib().rt_flat_bvh_stats(sc.flat, C.byref(n2), C.byref(d2), C.byref(n4), C.byref(d4)) == 0
+    assert 0 < d8.value <= d4.value + 1      # eight children a node: about two thirds of the four-wide tree's depth
+    assert rc <= n4.value
+    assert slack.value >= 0.0
+
+
 def test_scene_without_bvh(binding):
     sc = binding.Scene("cornell", 32, 32)
     n2, d2, n4, d4 = C.c_int(7), C.c_int(7), C.c_int(7), C.c_int(7)
