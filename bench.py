@@ -300,7 +300,10 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(tpath):
             try:
-                pm = json.load(open(tpath)).get(out["config"]["workload"])
+                table = json.load(open(tpath))
+                pm = table.get(out["config"]["workload"])
+                if pm is None:      # counted on a smaller frame of the same scene (the final scene: 1920x1080 x 64 spp); per-ray figures carry over
+                    pm = next((e for e in table.values() if e.get("stands_for") == workload), None)
             except Exception:
                 pm = None
         roof = {"bound": "valu", "kernel": kname, "kernel_ms": kernel_ms, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
@@ -334,15 +337,27 @@ def main():
                                                       "source": "profiles/r02_gather_rates.jsonl (110 MB and 1 GB tables)"}
                 roof["limits"] = limits
                 roof["hbm_algorithmic"] = {"bytes_per_ray": bpr, "achieved_GBs": ach_b, "peak_GBs": PEAK_HBM_GBS, "frac": ach_b / PEAK_HBM_GBS,
-                                           "note": "SURVEY 8(d) formula; the BVH sits in the Infinity Cache, HBM bandwidth does not bind"}
+                                           "note": "SURVEY 8(d) formula (every node and leaf row counted as if fetched from HBM); a frac above 1 means the "
+                                                   "L2s and the Infinity Cache absorbed the difference -- see fabric_measured for the bytes that left the L2s"}
             else:
                 roof.update({"bytes_per_ray": bpr, "hbm_peak_GBs": PEAK_HBM_GBS, "hbm_achieved_GBs": ach_b, "hbm_frac": ach_b / PEAK_HBM_GBS})
         # counters cannot be read in-process: the per-call HBM bytes and the PMC-derived shares come from the
         # committed rocprofv3 passes of this same command (tools/prof_round.sh -> profiles/pmc_summary.json), which
         # carry the commit they were taken at: after a kernel change they describe THAT build until the passes are re-run
         if pm:
-            roof["traffic"] = pm.get("traffic_bytes")
-            roof["pmc"] = {k: v for k, v in pm.items() if k != "traffic_bytes"}
+            kernel_s = kernel_ms * 1e-3
+            if pm.get("traffic_bytes_per_ray") and kernel_s > 0:
+                # measured bytes between the L2s and the fabric (FETCH_SIZE + WRITE_SIZE, corrected as tools/make_profiles.py says),
+                # per ray from the counter passes x this run's rays per launch, over this run's kernel time
+                roof["traffic"] = pm["traffic_bytes_per_ray"] * rays_per_launch
+                fab = roof["traffic"] / kernel_s / 1e9
+                roof["fabric_measured"] = {"bytes_per_ray": pm["traffic_bytes_per_ray"], "achieved_GBs": fab, "peak_GBs": PEAK_HBM_GBS, "frac": fab / PEAK_HBM_GBS,
+                                           "counted_on": pm.get("counted_on")}
+            if pm.get("lane_instructions_per_ray") and kernel_s > 0:
+                # lanes x VALU instructions per second against what 1024 SIMDs x 16 lanes issue per clock: the share of the
+                # chip's issue slots that carried a live lane (= VALU-busy share x lane efficiency)
+                roof["issue_ceiling_frac"] = pm["lane_instructions_per_ray"] * rays_per_launch / kernel_s / (N_CUS * 4 * 16 * CLOCK_GHZ * 1e9)
+            roof["pmc"] = {k: v for k, v in pm.items() if k not in ("traffic_bytes", "traffic_uncorrected_bytes", "rays")}
         out["roofline"] = roof
         return out
 

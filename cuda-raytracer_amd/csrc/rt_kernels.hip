@@ -26,6 +26,7 @@
 #include "rt_wavefront.h"
 #include "rt_wavefront2.h"
 #include "rt_wavefront8.h"
+#include "rt_wavefront4.h"
 #include "rt_reduce.h"
 
 /* feature sets the render kernel is compiled for (rt_host.h RT_F_*); a scene runs on the first one
@@ -52,7 +53,9 @@
 #define WF_MAX_POOLS 4
 #define WF_POOL_COUNT_WORDS (9 * 32)   /* per pool: one 128-B line of queue lengths + legacy head, then a line per band head */
 #ifndef WF_KERNEL_DEFAULT
-#define WF_KERNEL_DEFAULT 1     /* the intersect kernel wavefront renders use unless RT_WF_KERNEL says otherwise (wf_pick_kernel) */
+#define WF_KERNEL_DEFAULT 4     /* what wavefront renders run unless RT_WF_KERNEL says otherwise (wf_pick_kernel): 4 = the whole path in one
+                                 * persistent kernel (rt_wavefront4.h); 1 / 2 / 3 = intersect kernel + logic kernel, with the intersect
+                                 * kernel of rt_wavefront.h / rt_wavefront2.h / rt_wavefront8.h */
 #endif
 #ifndef WF_POOLS_DEFAULT
 #define WF_POOLS_DEFAULT 3
@@ -782,11 +785,13 @@ template <uint32_t V>
 static int wf_run_part(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t s1, uint32_t k0, uint32_t k1, int max_depth,
                        int background, float* accum);
 
+__global__ void wf_count_samples_kernel(unsigned long long* counters, unsigned long long n) { atomicAdd(&counters[1], n); }
+
 /* which intersect kernel: 2 = staged rays + queued leaves (rt_wavefront2.h), 1 = the first design (rt_wavefront.h); the
  * second packs a leaf item and a lane into 32 bits, an object and a group ordinal into the mailbox word, and its
  * all-feature variants have a shorter stack.  RT_WF_KERNEL in the environment overrides (A/B measurements). */
 template <uint32_t V>
-static int wf_pick_kernel(const rt_ctx* c)
+static int wf_pick_kernel(const rt_ctx* c, bool for_render = false)
 {
     const bool fits2 = c->n_bvh_items < (1 << WF2_ITEM_BITS) && c->n_objects < (1 << WF2_OBJ_BITS) - 1 && c->n_wf_groups <= WF2_MAX_GROUPS;
     int kernel = WF_KERNEL_DEFAULT == 2 && fits2 ? 2 : 1;
@@ -797,6 +802,9 @@ static int wf_pick_kernel(const rt_ctx* c)
     if (const char* e = std::getenv("RT_WF_KERNEL")) { const int v = std::atoi(e); if (v == 1 || (v == 2 && fits2) || (v == 3 && fits8)) kernel = v; }
     if (kernel == 2 && c->stack4 > wf2_lds_stack(V & ~RT_F_NOISE) + wf2_ovf(V & ~RT_F_NOISE)) kernel = 1;      /* a tree deeper than this variant's stack */
     if (!wf2_built(V)) kernel = 1;
+    /* 4 = the whole path in one persistent kernel (rt_wavefront4.h): renders only, any variant */
+    if (WF_KERNEL_DEFAULT == 4 && for_render) kernel = 4;
+    if (const char* e = std::getenv("RT_WF_KERNEL")) { const int v = std::atoi(e); if (v == 4 && for_render) kernel = 4; else if (v >= 1 && v <= 3 && kernel == 4) kernel = 1; }
     return kernel;
 }
 
@@ -852,8 +860,8 @@ static int wf_run_part(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t 
      * lanes.  Measured at 1080p (tools/refill_sweep.py), Grays/s at 16 / 24 / 32 / 40 / 48 / 56 idle lanes: final scene
      * (11 plain records) 2.78 / 2.93 / 3.01 / 3.04 / 3.01 / 2.90; 1M triangles (1 record) 2.08 / 2.10 / 2.12 / 2.12 / 2.12 / 2.09 */
     W.refill_min = 40;
-    const int kernel = wf_pick_kernel<V>(c);
-    if (kernel >= 2) W.refill_min = 12;        /* handing over a staged ray is a few LDS reads */
+    const int kernel = wf_pick_kernel<V>(c, true);
+    if (kernel == 2 || kernel == 3) W.refill_min = 12;        /* handing over a staged ray is a few LDS reads */
     W.bare = 0;
     W.box_abs = c->box_abs;
     /* XCD-affine claims of the queue (rt_wavefront.h): with the queue in slot order they raise the intersect kernel's L2
@@ -867,6 +875,33 @@ static int wf_run_part(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t 
     const int lds_stack = kernel == 2 ? wf2_lds_stack(V & ~RT_F_NOISE) : WF_LDS_STACK;
     const size_t lds = kernel == 3 ? (size_t)(c->depth8 < WF8_LDS_STACK ? c->depth8 : WF8_LDS_STACK) * RT_BLOCK * sizeof(uint2)
                                    : (size_t)(c->stack4 < lds_stack ? c->stack4 : lds_stack) * RT_BLOCK * sizeof(int);
+    if (kernel == 4) {
+        /* one launch: as many blocks as the chip holds at once (later ones would only find the work list empty) */
+        W.stream0 = 0;
+        HIPCHK(hipMemsetAsync(W.count, 0, WF_MAX_POOLS * WF_POOL_COUNT_WORDS * sizeof(uint32_t), c->stream));
+        c->last_wf_pools = 1;
+        if (max_depth <= 0) {
+            HIPCHK(hipMemsetAsync(W.sum, 0, n_slots * sizeof(float4), c->stream));
+            wf_count_samples_kernel<<<1, 1, 0, c->stream>>>(c->d_counters, (unsigned long long)n_pixels * (unsigned long long)(s1 - s0));
+        } else {
+            const size_t lds4 = lds + WF4_LDS_EXTRA_WORDS * sizeof(int);
+            int per_cu = 0, cus = 0;
+            if (background == RT_BG_BLACK) { HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wf_path_kernel<V, RT_BG_BLACK>, RT_BLOCK, lds4)); }
+            else { HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wf_path_kernel<V, RT_BG_SKY>, RT_BLOCK, lds4)); }
+            HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+            unsigned pblocks = (unsigned)(per_cu > 0 ? per_cu : 1) * (unsigned)(cus > 0 ? cus : 1);
+            if (const char* e = std::getenv("RT_WF_IBLOCKS")) { const int v = std::atoi(e); if (v > 0) pblocks = (unsigned)v; }
+            const unsigned all = (unsigned)((n_slots + RT_BLOCK - 1) / RT_BLOCK);
+            if (pblocks > all) pblocks = all;
+            if (std::getenv("RT_WF_DEBUG")) std::fprintf(stderr, "wf_run_part: path kernel, %u blocks (%d per CU), %zu B of LDS\n", pblocks, per_cu, lds4);
+            if (background == RT_BG_BLACK) wf_path_kernel<V, RT_BG_BLACK><<<dim3(pblocks), RT_BLOCK, lds4, c->stream>>>(c->ds, W, w, h, s0, s1, k0, k1, max_depth, c->d_counters);
+            else wf_path_kernel<V, RT_BG_SKY><<<dim3(pblocks), RT_BLOCK, lds4, c->stream>>>(c->ds, W, w, h, s0, s1, k0, k1, max_depth, c->d_counters);
+        }
+        HIPCHK(hipGetLastError());
+        wf_finalize_kernel<<<dim3((n_pixels + RT_BLOCK - 1) / RT_BLOCK), RT_BLOCK, 0, c->stream>>>(W, accum);
+        HIPCHK(hipGetLastError());
+        return RT_OK;
+    }
     /* Pools.  The slots are cut into three pools by sample stream and each pool runs its own intersect / logic loop
      * on a stream of its own, with a persistent intersect grid of a third of the size: while one pool's intersect
      * launch drains (its waves waiting for their last rays) or its logic kernel waits on memory, the other pools'

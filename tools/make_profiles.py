@@ -1,20 +1,23 @@
-"""Usage: python tools/make_profiles.py TAG [node4_rows_per_ray leaf_rows_per_ray]   (the two numbers from tools/stamps.py on the triangle scene)
-Copy the rocprofv3 summaries of a tools/prof_round.sh run from gpurun_out/<tag>/ into profiles/ (tracked):
-kernel-trace stats, one text file of PMC sums per kernel, and profiles/hbm_traffic.json (bytes per render call,
-read by bench.py as roofline.traffic).  FETCH_SIZE / WRITE_SIZE are in KiB.  Corrections (MI355X_MICROARCH.md,
-HBM): the Cornell megakernel reads its accumulation buffer as a coalesced stream, for which gfx950 tallies half
-the bytes -> FETCH doubled; the wavefront kernels gather 64-byte rows, and there FETCH_SIZE agrees with
-TCC_MISS x 64 B (656 GB vs 618 GB).  Calibrated in round 2 (tools/ubench/gather.hip, profiles/r02_gather_pmc.txt): FETCH_SIZE
-= 64 B x (requests that miss the L2), whether the request is a 64-B row or a 128-B row, and whether it is then served by the
-Infinity Cache or by HBM.  So for the wavefront kernels the bytes that really cross the fabric are FETCH_SIZE x
-(128 N + 64 L) / (64 (N + L)) with N four-wide node rows and L leaf rows per ray (tools/stamps.py).  Every entry is stamped
-with the commit the passes were taken at."""
-import collections, csv, glob, json, os, shutil, sys
+"""Usage: python tools/make_profiles.py TAG [OUT_PREFIX]
+Copy the rocprofv3 summaries of a tools/prof_round.sh run (both parts) from gpurun_out/<TAG>/ into profiles/ (tracked) as
+<OUT_PREFIX>_* (default: TAG): kernel-trace stats, one text file of PMC sums per kernel and workload, and
+profiles/pmc_summary.json, which bench.py reads for roofline.traffic / roofline.pmc / fabric_measured / issue_ceiling_frac.
+One entry per line of the default bench.py run: cornell (headline), cornell_smoke, tri_mesh, final.  The final scene's passes
+are taken at 1920x1080 x 64 spp (the configs[4] frame is a minute a pass); everything bench.py uses from an entry is per ray,
+and the entry says which command it was counted on.
+
+FETCH_SIZE / WRITE_SIZE are in KiB.  Corrections (MI355X_MICROARCH.md, HBM): the megakernel reads its accumulation buffer as
+a coalesced stream, for which gfx950 tallies half the bytes -> FETCH doubled; the wavefront kernels gather 64-byte rows, and
+there FETCH_SIZE agrees with TCC_MISS x 64 B.  Calibrated in round 2 (tools/ubench/gather.hip, profiles/r02_gather_pmc.txt):
+FETCH_SIZE = 64 B x (requests that miss the L2), whether the request is a 64-B row or a 128-B row, and whether it is then
+served by the Infinity Cache or by HBM.  So for the intersect kernel the bytes that really cross the fabric are FETCH_SIZE x
+(128 N + 64 L) / (64 (N + L)) with N four-wide node rows and L leaf rows per ray (tools/stamps.py, run by prof_round.sh).
+Every entry is stamped with the commit the passes were taken at."""
+import collections, csv, glob, json, os, re, sys
 import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-rows_node4 = float(sys.argv[2]) if len(sys.argv) > 3 else 17.75      # measured (1M triangles, 1920x1080): tools/stamps.py
-rows_leaf = float(sys.argv[3]) if len(sys.argv) > 3 else 7.36
+prefix = sys.argv[2] if len(sys.argv) > 2 else tag
 try:
     commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
     if subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "cuda-raytracer_amd"], text=True).strip():
@@ -24,37 +27,67 @@ except Exception:
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
+KERNELS = ("wf_", "render_kernel", "resolve_kernel")
+
 
 def sums(d):
     acc = collections.defaultdict(lambda: [0.0, 0])
     for f in glob.glob(os.path.join(src, d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
-            if not any(s in k for s in ("wf_", "render_kernel")):
+            if not any(s in k for s in KERNELS[:2]):
                 continue
             a = acc[(k, r["Counter_Name"])]
             a[0] += float(r["Counter_Value"]); a[1] += 1
     return acc
 
-for name in ("trace_default", "trace_tri"):
+
+def bench_line(log):
+    """the JSON line bench.py printed under the profiler (rays of the counted command = value x time)"""
+    try:
+        for line in open(os.path.join(src, log)):
+            if line.startswith("{") and '"metric"' in line:
+                return json.loads(line)
+    except OSError:
+        pass
+    return None
+
+
+def rows_per_ray(name):
+    try:
+        m = re.search(r"rows fetched per ray: ([0-9.]+) four-wide nodes .* \+ ([0-9.]+) leaf", open(os.path.join(src, name)).read())
+        return (float(m.group(1)), float(m.group(2))) if m else None
+    except OSError:
+        return None
+
+
+for name in ("trace_default", "trace_tri", "trace_final"):
     for f in glob.glob(os.path.join(src, name, "**", "*kernel_stats.csv"), recursive=True):
         rows = list(csv.reader(open(f)))
-        keep = [rows[0]] + [r for r in rows[1:] if any(s in r[0] for s in ("wf_", "render_kernel", "resolve_kernel"))]
-        with open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, name)), "w", newline="") as o:
+        keep = [rows[0]] + [r for r in rows[1:] if any(s in r[0] for s in KERNELS)]
+        with open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (prefix, name)), "w", newline="") as o:
             csv.writer(o, quoting=csv.QUOTE_ALL).writerows(keep)
 
+WORKLOADS = (("cornell", ["cornell_fetch", "cornell_write", "cornell_sq", "cornell_sq2", "cornell_grbm"]),
+             ("smoke", ["smoke_fetch", "smoke_write", "smoke_sq", "smoke_grbm"]),
+             ("tri", ["tri_fetch", "tri_write", "tri_tcc", "tri_sq", "tri_grbm"]),
+             ("final", ["final_fetch", "final_write", "final_tcc", "final_sq", "final_grbm"]))
 allsum = {}
-for wl, dirs in (("cornell", ["cornell_fetch", "cornell_write", "cornell_sq", "cornell_sq2"]),
-                 ("tri", ["tri_fetch", "tri_write", "tri_tcc", "tri_sq", "tri_grbm"])):
-    with open(os.path.join(dst, "%s_%s_pmc.txt" % (tag, wl)), "w") as o:
-        o.write("# rocprofv3 --pmc sums over all launches of one bench.py render call (tools/prof_round.sh); one pass per counter group\n")
-        for d in dirs:
-            a = sums(d)
-            for (k, c), (v, n) in sorted(a.items()):
-                o.write("%-34s %-24s sum=%.6g launches=%d\n" % (k[:34], c, v, n))
-                allsum[(wl, k.split("<")[0].replace("void ", ""), c)] = v
+for wl, dirs in WORKLOADS:
+    lines = []
+    for d in dirs:
+        for (k, c), (v, n) in sorted(sums(d).items()):
+            lines.append("%-34s %-24s sum=%.6g launches=%d\n" % (k[:34], c, v, n))
+            allsum[(wl, k.split("<")[0].replace("void ", ""), c)] = v
+    if lines:
+        with open(os.path.join(dst, "%s_%s_pmc.txt" % (prefix, wl)), "w") as o:
+            o.write("# rocprofv3 --pmc sums over all launches of one bench.py render call (tools/prof_round.sh); one pass per counter group\n")
+            o.writelines(lines)
+
+
 def g(wl, k, c):
     return allsum.get((wl, k, c), 0.0)
+
 
 def derived(wl, k):
     """VALU busy share of the SIMDs (SQ_ACTIVE_INST_VALU counts quad-cycles; GRBM_GUI_ACTIVE is summed over the
@@ -71,20 +104,42 @@ def derived(wl, k):
         out["l2_hit_rate"] = g(wl, k, "TCC_HIT_sum") / g(wl, k, "TCC_REQ_sum")
     return out
 
-gather_fix = (128.0 * rows_node4 + 64.0 * rows_leaf) / (64.0 * (rows_node4 + rows_leaf))
-tri_fetch = sum(v for (wl, k, c), v in allsum.items() if wl == "tri" and c == "FETCH_SIZE") * 1024.0
-tri_fetch_isect = g("tri", "wf_intersect_kernel", "FETCH_SIZE") * 1024.0
-tri_write = sum(v for (wl, k, c), v in allsum.items() if wl == "tri" and c == "WRITE_SIZE") * 1024.0
-summary = {
-    "cornell_1024x1024_1024spp": dict(derived("cornell", "render_kernel"), kernel="render_kernel", source=tag, commit=commit,
-        traffic_bytes=(2.0 * g("cornell", "render_kernel", "FETCH_SIZE") + g("cornell", "render_kernel", "WRITE_SIZE")) * 1024.0),
-    "tri_mesh_1920x1080_256spp": dict(derived("tri", "wf_intersect_kernel"), kernel="wf_intersect_kernel", source=tag, commit=commit,
+
+def rays_of(log):
+    j = bench_line(log)
+    return (j["value"] * 1e6 * j["ms_per_step"] * 1e-3 * j["steps"], j["config"]["workload"]) if j else (None, None)
+
+
+summary = {}
+for wl, key in (("cornell", None), ("smoke", None)):
+    rays, workload = rays_of("%s_fetch.log" % wl)
+    if not rays or not g(wl, "render_kernel", "FETCH_SIZE"):
+        continue
+    traffic = (2.0 * g(wl, "render_kernel", "FETCH_SIZE") + g(wl, "render_kernel", "WRITE_SIZE")) * 1024.0
+    summary[workload] = dict(derived(wl, "render_kernel"), kernel="render_kernel", source=tag, commit=commit, counted_on=workload, rays=rays,
+                             traffic_bytes=traffic, traffic_bytes_per_ray=traffic / rays,
+                             # active lanes x VALU instructions (SQ_THREAD_CYCLES_VALU counts lanes x quad-cycles): bench.py divides by
+                             # its own kernel time and by 1024 SIMDs x 16 lanes x clock -> issue_ceiling_frac
+                             lane_instructions_per_ray=g(wl, "render_kernel", "SQ_THREAD_CYCLES_VALU") / rays)
+for wl, stamps, stands_for in (("tri", "stamps_tri.txt", "tri_mesh"), ("final", "stamps_final.txt", "final")):
+    rays, workload = rays_of("%s_fetch.log" % wl)
+    rows = rows_per_ray(stamps)
+    if not rays or not rows or not g(wl, "wf_intersect_kernel", "FETCH_SIZE"):
+        continue
+    n4, lf = rows
+    gather_fix = (128.0 * n4 + 64.0 * lf) / (64.0 * (n4 + lf))
+    fetch = sum(v for (w, k, c), v in allsum.items() if w == wl and c == "FETCH_SIZE") * 1024.0
+    fetch_isect = g(wl, "wf_intersect_kernel", "FETCH_SIZE") * 1024.0
+    write = sum(v for (w, k, c), v in allsum.items() if w == wl and c == "WRITE_SIZE") * 1024.0
+    traffic = fetch - fetch_isect + fetch_isect * gather_fix + write
+    summary[workload] = dict(derived(wl, "wf_intersect_kernel"), kernel="wf_intersect_kernel", source=tag, commit=commit, counted_on=workload,
+        stands_for=stands_for, rays=rays,
         # path state in the intersect kernel: ray_o + ray_d read by the refill, hit written: three 16-B pieces per ray, and the
         # queue stays sorted by slot, so four neighbouring rays share each 64-B line: 3 / 4 requests per ray
-        rows_per_ray={"node4_128B": rows_node4, "leaf_64B": rows_leaf, "state_64B": 0.75, "source": "tools/stamps.py (diagnostic build)"},
-        traffic_uncorrected_bytes=tri_fetch + tri_write,
-        traffic_bytes=tri_fetch - tri_fetch_isect + tri_fetch_isect * gather_fix + tri_write,
-        fetch_correction_intersect=gather_fix),
-}
+        rows_per_ray={"node4_128B": n4, "leaf_64B": lf, "state_64B": 0.75, "source": "tools/stamps.py (diagnostic build)"},
+        traffic_uncorrected_bytes=fetch + write, traffic_bytes=traffic, traffic_bytes_per_ray=traffic / rays,
+        fetch_correction_intersect=gather_fix,
+        logic_kernel=derived(wl, "wf_logic_kernel"),
+        lane_instructions_per_ray=(g(wl, "wf_intersect_kernel", "SQ_THREAD_CYCLES_VALU") + g(wl, "wf_logic_kernel", "SQ_THREAD_CYCLES_VALU")) / rays)
 json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))

@@ -36,7 +36,7 @@ if os.environ.get("RT_INTEGRATOR") == "2" or (sc.flat.contents.n_bvh_nodes > 0 a
         print("  trips with a node step %.3f (%.1f lanes each), with a primitive step %.3f (%.1f lanes each); stalled lanes/trip %.1f; cycles/trip %.0f"
               % (d[5] / d[0], d[2] / max(1.0, d[5]), d[6] / d[0], d[3] / max(1.0, d[6]), d[4] / d[0], d[7] / d[0]))
     print("  rows fetched per ray: %.2f four-wide nodes (128-B rows) + %.2f leaf primitives (64-B rows)" % (d[2] / c.rays, d[3] / c.rays))
-    if hasattr(B.lib(), "rt_debug_sections") and os.environ.get("RT_WF_KERNEL", "2") == "2":
+    if hasattr(B.lib(), "rt_debug_sections") and os.environ.get("RT_WF_KERNEL", "1") == "2":
         sec = (C.c_ulonglong * 16)()
         B.lib().rt_debug_sections.argtypes = [C.c_void_p, C.c_void_p]
         B.lib().rt_debug_sections(ctx.handle, sec)
