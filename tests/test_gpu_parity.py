@@ -667,6 +667,7 @@ def test_wavefront_failure_leaves_the_context_usable(binding, gpu_ctx, monkeypat
     W, H, spp = 64, 48, 6
     sc = binding.Scene("final", W, H, 8)
     gpu_ctx.upload(sc)
+    monkeypatch.setenv("RT_WF_KERNEL", "1")          # the intersect + logic loop (the one-kernel form has no host loop to leave)
     good = render_gpu(gpu_ctx, binding, sc, W, H, 0, spp, 5, integrator="wavefront")
     monkeypatch.setenv("RT_WF_DEBUG_MAX_ITERS", "0")
     with pytest.raises(binding.RtError) as e:
