@@ -432,6 +432,7 @@ struct rt_ctx {
     WfState wf = {};
     void* wf_mem = nullptr;
     size_t wf_slots_cap = 0;
+    bool wf_cap_full = false;       /* wf_mem holds the full path state (two-kernel forms, rt_trace_rays_wavefront), not only the slot sums */
     size_t wf_slots_target = RT_WF_SLOTS;   /* paths to keep in flight */
     uint32_t* wf_host_count = nullptr;   /* pinned: 4 words of readback per pool, then the pools' first queue lengths */
     hipStream_t wf_streams[WF_MAX_POOLS] = {};        /* the pools' streams: found to run side by side (wf_pick_streams) */
@@ -749,14 +750,17 @@ static int wf_pick_streams(rt_ctx* c)
     return RT_OK;
 }
 
-static int wf_reserve(rt_ctx* c, size_t n_slots)
+/* sums_only: the one-kernel form (rt_wavefront4.h) keeps no path state and no queues in HBM, only a slot's sum (16 B a slot
+ * instead of 88) */
+static int wf_reserve(rt_ctx* c, size_t n_slots, bool sums_only = false)
 {
     if (!c->wf_host_count) HIPCHK(hipHostMalloc((void**)&c->wf_host_count, 5 * WF_MAX_POOLS * sizeof(uint32_t), hipHostMallocDefault));
     for (hipEvent_t& e : c->wf_ev) if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    if (n_slots > c->wf_slots_cap) {
+    if (n_slots > c->wf_slots_cap || (!sums_only && !c->wf_cap_full)) {
         HIPCHK(hipStreamSynchronize(c->stream));
         if (c->wf_mem) { (void)hipFree(c->wf_mem); c->wf_mem = nullptr; c->wf_slots_cap = 0; }
-        const size_t bytes = n_slots * (5 * sizeof(float4) + 2 * sizeof(uint32_t)) + WF_MAX_POOLS * WF_POOL_COUNT_WORDS * sizeof(uint32_t) + 128
+        const size_t per_slot = sums_only ? sizeof(float4) : 5 * sizeof(float4) + 2 * sizeof(uint32_t);
+        const size_t bytes = n_slots * per_slot + WF_MAX_POOLS * WF_POOL_COUNT_WORDS * sizeof(uint32_t) + 128
                              + (n_slots / WF_SPAN + 2 * WF_MAX_POOLS + 1) * sizeof(uint32_t);
         if (hipMalloc(&c->wf_mem, bytes) != hipSuccess) {
             (void)hipGetLastError();
@@ -765,17 +769,24 @@ static int wf_reserve(rt_ctx* c, size_t n_slots)
             return RT_ERR_HIP;
         }
         c->wf_slots_cap = n_slots;
+        c->wf_cap_full = !sums_only;
     }
-    /* carve: five float4 arrays, two queues, then the counters */
+    /* carve: five float4 arrays and two queues (or the sums alone), then the counters */
     char* p = (char*)c->wf_mem;
     const size_t cap = c->wf_slots_cap;
-    c->wf.ray_o = (float4*)p; p += cap * sizeof(float4);
-    c->wf.ray_d = (float4*)p; p += cap * sizeof(float4);
-    c->wf.att   = (float4*)p; p += cap * sizeof(float4);
-    c->wf.sum   = (float4*)p; p += cap * sizeof(float4);
-    c->wf.hit   = (float4*)p; p += cap * sizeof(float4);
-    c->wf.queue[0] = (uint32_t*)p; p += cap * sizeof(uint32_t);
-    c->wf.queue[1] = (uint32_t*)p; p += cap * sizeof(uint32_t);
+    if (c->wf_cap_full) {
+        c->wf.ray_o = (float4*)p; p += cap * sizeof(float4);
+        c->wf.ray_d = (float4*)p; p += cap * sizeof(float4);
+        c->wf.att   = (float4*)p; p += cap * sizeof(float4);
+        c->wf.sum   = (float4*)p; p += cap * sizeof(float4);
+        c->wf.hit   = (float4*)p; p += cap * sizeof(float4);
+        c->wf.queue[0] = (uint32_t*)p; p += cap * sizeof(uint32_t);
+        c->wf.queue[1] = (uint32_t*)p; p += cap * sizeof(uint32_t);
+    } else {
+        c->wf.ray_o = c->wf.ray_d = c->wf.att = c->wf.hit = nullptr;
+        c->wf.queue[0] = c->wf.queue[1] = nullptr;
+        c->wf.sum = (float4*)p; p += cap * sizeof(float4);
+    }
     c->wf.count = (uint32_t*)(((uintptr_t)p + 127u) & ~(uintptr_t)127u);      /* the counters' lines are 128-B aligned */
     c->wf.scan = c->wf.count + WF_MAX_POOLS * WF_POOL_COUNT_WORDS;             /* cap / WF_SPAN + 2 * WF_MAX_POOLS + 1 words */
     return RT_OK;
@@ -844,12 +855,13 @@ static int wf_run_part(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t 
     if (streams < 1) streams = 1;
     while ((size_t)n_pixels * streams > 0xffffffffull) streams = (streams + 1) / 2;    /* slot indices are 32-bit */
     size_t n_slots = (size_t)n_pixels * streams;
-    int rc = wf_reserve(c, n_slots);
+    const int kernel = wf_pick_kernel<V>(c, true);
+    int rc = wf_reserve(c, n_slots, kernel == 4);
     while (rc && streams > 1) {            /* no room for that many paths: halve, and remember */
         streams = (streams + 1) / 2;
         n_slots = (size_t)n_pixels * streams;
         c->wf_slots_target = n_slots;
-        rc = wf_reserve(c, n_slots);
+        rc = wf_reserve(c, n_slots, kernel == 4);
     }
     if (rc) return rc;
     WfState& W = c->wf;
@@ -860,7 +872,6 @@ static int wf_run_part(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t 
      * lanes.  Measured at 1080p (tools/refill_sweep.py), Grays/s at 16 / 24 / 32 / 40 / 48 / 56 idle lanes: final scene
      * (11 plain records) 2.78 / 2.93 / 3.01 / 3.04 / 3.01 / 2.90; 1M triangles (1 record) 2.08 / 2.10 / 2.12 / 2.12 / 2.12 / 2.09 */
     W.refill_min = 40;
-    const int kernel = wf_pick_kernel<V>(c, true);
     if (kernel == 2 || kernel == 3) W.refill_min = 12;        /* handing over a staged ray is a few LDS reads */
     W.bare = 0;
     W.box_abs = c->box_abs;

@@ -22,13 +22,22 @@
 #define RT_WAVEFRONT4_H
 #include "rt_wavefront.h"
 
-#ifndef WF4_WAVES
-#define WF4_WAVES 4
+/* waves per SIMD: measured (1080p; 1M triangles x 256 spp / final scene x 64 spp, Grays/s) 3 waves 3.20 / 3.69, 4 waves 3.19 / 4.20,
+ * 5 waves 3.51 / 3.92 -- the triangle variant fits 96 registers, the general ones spill there */
+#ifndef WF4_GENERAL_WAVES
+#define WF4_GENERAL_WAVES 4
+#endif
+#ifndef WF4_TRI_WAVES
+#define WF4_TRI_WAVES 5
+#endif
+constexpr int wf4_waves(uint32_t F) { return (F & ~(RT_F_BVH | RT_F_TRI | RT_F_PLANAR)) == 0 ? WF4_TRI_WAVES : WF4_GENERAL_WAVES; }
+#ifndef WF4_CHUNKS_PER_WAVE
+#define WF4_CHUNKS_PER_WAVE 256
 #endif
 #define WF4_LDS_EXTRA_WORDS (7 * RT_BLOCK)      /* per lane: attenuation xyz, sum xyz; per wave: 64 ints for the ball draw */
 
 template <uint32_t F, int BG>
-__global__ __launch_bounds__(RT_BLOCK, WF4_WAVES) void wf_path_kernel(DScene S, WfState W, int Wd, int Hd, uint32_t s_begin, uint32_t s_end,
+__global__ __launch_bounds__(RT_BLOCK, wf4_waves(F)) void wf_path_kernel(DScene S, WfState W, int Wd, int Hd, uint32_t s_begin, uint32_t s_end,
                                                                       uint32_t k0, uint32_t k1, int max_depth,
                                                                       unsigned long long* __restrict__ counters)
 {
@@ -68,13 +77,16 @@ __global__ __launch_bounds__(RT_BLOCK, WF4_WAVES) void wf_path_kernel(DScene S, 
     uint32_t n_rays = 0;
     bool drained = false;
     uint32_t chunk_next = 0, chunk_end = 0;
-    uint32_t chunk = n_queue / (gridDim.x * (RT_BLOCK / 64) * 2u);
-    chunk = chunk < 16u ? 16u : (chunk > (uint32_t)WF_CHUNK ? (uint32_t)WF_CHUNK : chunk);
+    /* a slot is many rays here (all its samples), and a wave owns its chunk to the end: chunks are kept small enough that
+     * every wave takes a few hundred of them, or the waves with the heaviest last chunks decide when the call ends
+     * (1M triangles x 256 spp with 32 M slots: 2.93 Grays/s in chunks of 1024 against 3.19 with 128 M slots) */
+    uint32_t chunk = n_queue / (gridDim.x * (RT_BLOCK / 64) * (uint32_t)WF4_CHUNKS_PER_WAVE);
+    chunk = chunk < 64u ? 64u : (chunk > (uint32_t)WF_CHUNK ? (uint32_t)WF_CHUNK : chunk);
     const uint32_t af_chunks = (n_queue + chunk - 1u) / chunk;
     const uint32_t af_streams = W.n_slots / (W.n_pixels ? W.n_pixels : 1u);
     uint32_t af_cps = (af_chunks + (af_streams ? af_streams : 1u) - 1u) / (af_streams ? af_streams : 1u);
     af_cps = af_cps < 8u ? 8u : af_cps;
-    int band = (int)(blockIdx.x & 7u), band_tried = 0;
+    int band = (int)(blockIdx.x & 7u);
 #ifdef RT_STAMPS
     unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long dg_t0 = __builtin_amdgcn_s_memtime();
@@ -192,7 +204,10 @@ __global__ __launch_bounds__(RT_BLOCK, WF4_WAVES) void wf_path_kernel(DScene S, 
                             if (left > most) { most = left; where = x; }
                         }
                         where = __builtin_amdgcn_readfirstlane(where);
-                        if (where < 0 || ++band_tried > 32) { drained = true; chunk_next = chunk_end = n_queue; }
+                        /* every pass of this loop advances a head, and a head only moves up: the loop ends when all eight are
+                         * past their bands.  (No cap on the passes as in wf_intersect_kernel: a wave that gave up early here
+                         * would leave slots that no later launch picks up.) */
+                        if (where < 0) { drained = true; chunk_next = chunk_end = n_queue; }
                         else band = where;
                     }
                 }
