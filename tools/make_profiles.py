@@ -124,22 +124,25 @@ for wl, key in (("cornell", None), ("smoke", None)):
 for wl, stamps, stands_for in (("tri", "stamps_tri.txt", "tri_mesh"), ("final", "stamps_final.txt", "final")):
     rays, workload = rays_of("%s_fetch.log" % wl)
     rows = rows_per_ray(stamps)
-    if not rays or not rows or not g(wl, "wf_intersect_kernel", "FETCH_SIZE"):
+    # the kernel that walks the trees: the one-kernel form's wf_path_kernel (default) or the two-kernel form's wf_intersect_kernel
+    main = "wf_path_kernel" if g(wl, "wf_path_kernel", "FETCH_SIZE") else "wf_intersect_kernel"
+    if not rays or not rows or not g(wl, main, "FETCH_SIZE"):
         continue
     n4, lf = rows
     gather_fix = (128.0 * n4 + 64.0 * lf) / (64.0 * (n4 + lf))
     fetch = sum(v for (w, k, c), v in allsum.items() if w == wl and c == "FETCH_SIZE") * 1024.0
-    fetch_isect = g(wl, "wf_intersect_kernel", "FETCH_SIZE") * 1024.0
+    fetch_isect = g(wl, main, "FETCH_SIZE") * 1024.0
     write = sum(v for (w, k, c), v in allsum.items() if w == wl and c == "WRITE_SIZE") * 1024.0
     traffic = fetch - fetch_isect + fetch_isect * gather_fix + write
-    summary[workload] = dict(derived(wl, "wf_intersect_kernel"), kernel="wf_intersect_kernel", source=tag, commit=commit, counted_on=workload,
+    summary[workload] = dict(derived(wl, main), kernel=main, source=tag, commit=commit, counted_on=workload,
         stands_for=stands_for, rays=rays,
-        # path state in the intersect kernel: ray_o + ray_d read by the refill, hit written: three 16-B pieces per ray, and the
-        # queue stays sorted by slot, so four neighbouring rays share each 64-B line: 3 / 4 requests per ray
-        rows_per_ray={"node4_128B": n4, "leaf_64B": lf, "state_64B": 0.75, "source": "tools/stamps.py (diagnostic build)"},
+        # path state: none in the one-kernel form (a 16-B sum per slot at its end); in the two-kernel form ray_o + ray_d read by
+        # the refill and hit written, three 16-B pieces per ray with four neighbouring rays sharing each 64-B line
+        rows_per_ray={"node4_128B": n4, "leaf_64B": lf, "state_64B": 0.0 if main == "wf_path_kernel" else 0.75, "source": "tools/stamps.py (diagnostic build)"},
         traffic_uncorrected_bytes=fetch + write, traffic_bytes=traffic, traffic_bytes_per_ray=traffic / rays,
         fetch_correction_intersect=gather_fix,
-        logic_kernel=derived(wl, "wf_logic_kernel"),
-        lane_instructions_per_ray=(g(wl, "wf_intersect_kernel", "SQ_THREAD_CYCLES_VALU") + g(wl, "wf_logic_kernel", "SQ_THREAD_CYCLES_VALU")) / rays)
+        logic_kernel=derived(wl, "wf_logic_kernel") if g(wl, "wf_logic_kernel", "SQ_WAVES") else None,
+        valu_instructions_per_ray=g(wl, main, "SQ_INSTS_VALU") / rays,
+        lane_instructions_per_ray=(g(wl, main, "SQ_THREAD_CYCLES_VALU") + g(wl, "wf_logic_kernel", "SQ_THREAD_CYCLES_VALU")) / rays)
 json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))

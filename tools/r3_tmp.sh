@@ -1,6 +1,10 @@
 set -e
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$1; mkdir -p $O
-for s in "tri_mesh 1920 1080 8 1000000" "final 1920 1080 16 100"; do
-RT_AMD_LIB=tools/diag/librt_amd_stampsrf.so RT_STAMPS_REFILL=1 timeout -k 10 200 python3 tools/stamps.py $s 2>/dev/null | tee -a $O/stamps.txt
+run() { echo "== $*" | tee -a $O/rates.txt; env "$@" timeout -k 10 150 python3 tools/wf_rate.py $SCENE 2>/dev/null | tee -a $O/rates.txt; }
+for SCENE in "final 100 1920 1080 64" "cornell_cluster 0 1920 1080 64" "tri_mesh 1000000 1920 1080 64"; do
+  run A=0
+  run RT_AMD_LIB=tools/diag/librt_amd_e1.so
+  run RT_AMD_LIB=tools/diag/librt_amd_e6.so
+  run RT_AMD_LIB=tools/diag/librt_amd_e20.so
 done
