@@ -266,7 +266,7 @@ def main():
                        "width": W, "height": H, "spp_per_gpu": spp if scaling == "weak" else spp / world, "spp_total": spp_total, "max_depth": 100,
                        "background": "sky" if background else "black", "bvh": has_bvh,
                        "integrator": "wavefront" if wavefront else "megakernel",
-                       "wf_pools": int(c.wf_pools) if wavefront else None,
+                       "wf_kernel": int(c.wf_kernel) if wavefront else None, "wf_pools": int(c.wf_pools) if wavefront else None,
                        "parallelism": ("spp-shard x%d (%s) + %s" % (world, scaling, "RCCL reduce" if backend == "nccl" else "gloo reduce (REHEARSAL, ranks share GPUs)")) if world > 1 else "single GPU"},
             "samples_per_s": samples / dt, "rays_per_sample": rays / max(1.0, samples),
             "image_mean": mean_rgb, "image_finite": finite,
@@ -285,9 +285,10 @@ def main():
             out["cpu_baseline"] = None
         # roofline of the dominant kernel, duration from HIP events recorded on its own stream inside the library.
         # megakernel: render_kernel is the launch, bound by VALU issue (its tables sit in the scalar cache).
-        # wavefront: the event pair spans the whole intersect/logic loop (the pools' kernels overlap, so per-kernel
-        # durations of a trace add up to more than the call).  Three limits sit close together on that loop and all
-        # three are reported under "limits" (DESIGN.md section 6): VALU issue of the intersect kernel (PMC pass), the
+        # wavefront: ONE persistent kernel per call (wf_path_kernel, rt_wavefront4.h), so the event pair is that kernel's
+        # duration and agrees with the trace (profiles/r03_trace_tri_kernel_stats.csv); with RT_WF_KERNEL=1..3 it spans the
+        # intersect/logic loop of the pools.  Three limits are reported under "limits" (DESIGN.md section 6): VALU issue of
+        # the kernel (PMC pass: saturated in the one-kernel form), the
         # rate at which a CU's address unit takes divergent 16-byte lane loads (tools/ubench/gather.hip with an
         # L2-resident table: about one lane per clock per CU), and the rate at which L2 misses leave the L2s (same
         # ubench, 110 MB and 1 GB tables: 58 G row requests/s chip-wide).  The line's own bound is the tightest one,
@@ -295,7 +296,8 @@ def main():
         # peak.  The algorithmic HBM-bytes fraction SURVEY 8(d) defines is carried under "hbm_algorithmic"; the BVH
         # sits in the Infinity Cache and HBM bandwidth does not bind.
         rays_per_launch = rays / world / max(1, c.render_launches)
-        kname = "wf_intersect_kernel + wf_logic_kernel loop" if wavefront else "render_kernel"
+        one_kernel = wavefront and int(c.wf_kernel) == 4
+        kname = ("wf_path_kernel" if one_kernel else "wf_intersect_kernel + wf_logic_kernel loop") if wavefront else "render_kernel"
         pm = None
         tpath = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(tpath):
@@ -321,9 +323,9 @@ def main():
                                                    "source": "profiles/pmc_summary.json (rocprofv3 --pmc pass of this command)"}}
                 if rows:
                     rays_s = rays_per_launch / (kernel_ms * 1e-3)
-                    # 16-byte lane loads and stores per ray: 7 per four-wide node row, 4 per leaf row, and the path
-                    # state (refill 2 + hit 1 in the intersect kernel; 5 loads + 4 stores in the logic kernel)
-                    lane_ops = 7.0 * rows["node4_128B"] + 4.0 * rows["leaf_64B"] + 12.0
+                    # 16-byte lane loads and stores per ray: 7 per four-wide node row, 4 per leaf row, and in the two-kernel
+                    # forms the path state (refill 2 + hit 1 in the intersect kernel; 5 loads + 4 stores in the logic kernel)
+                    lane_ops = 7.0 * rows["node4_128B"] + 4.0 * rows["leaf_64B"] + (0.0 if one_kernel else 12.0)
                     per_clk_cu = rays_s * lane_ops / (N_CUS * CLOCK_GHZ * 1e9)
                     limits["vector_memory_address_rate"] = {
                         "lane_16B_accesses_per_ray": lane_ops, "achieved_per_clock_per_CU": per_clk_cu, "peak_per_clock_per_CU": TA_LANES_PER_CLOCK,

@@ -67,7 +67,8 @@ class RtHitRecord(C.Structure):
 class RtCounters(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("render_ms", C.c_double),
                 ("last_render_ms", C.c_double), ("render_launches", C.c_uint32), ("last_integrator", C.c_uint32),
-                ("wf_pools", C.c_uint32), ("wf_streams_found", C.c_uint32)]
+                ("wf_pools", C.c_uint32), ("wf_streams_found", C.c_uint32),
+                ("wf_kernel", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 # numpy dtype with the layout of rt_scatter_record / rto_scatter_out (60 bytes)

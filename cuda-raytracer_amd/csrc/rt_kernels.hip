@@ -428,6 +428,7 @@ struct rt_ctx {
     int integrator = RT_INTEGRATOR_AUTO;
     int last_integrator = 0;          /* form the latest render call ran in (rt_counters) */
     int last_wf_pools = 0;            /* pools the latest wavefront call ran as (rt_counters) */
+    int last_wf_kernel = 0;           /* and its form (wf_pick_kernel) */
     /* wavefront path state (rt_wavefront.h), allocated on first use and kept */
     WfState wf = {};
     void* wf_mem = nullptr;
@@ -814,8 +815,9 @@ static int wf_pick_kernel(const rt_ctx* c, bool for_render = false)
     if (kernel == 2 && c->stack4 > wf2_lds_stack(V & ~RT_F_NOISE) + wf2_ovf(V & ~RT_F_NOISE)) kernel = 1;      /* a tree deeper than this variant's stack */
     if (!wf2_built(V)) kernel = 1;
     /* 4 = the whole path in one persistent kernel (rt_wavefront4.h): renders only, any variant */
-    if (WF_KERNEL_DEFAULT == 4 && for_render) kernel = 4;
-    if (const char* e = std::getenv("RT_WF_KERNEL")) { const int v = std::atoi(e); if (v == 4 && for_render) kernel = 4; else if (v >= 1 && v <= 3 && kernel == 4) kernel = 1; }
+    const char* e4 = std::getenv("RT_WF_KERNEL");
+    const int v4 = e4 ? std::atoi(e4) : 0;
+    if (for_render && (v4 == 4 || (WF_KERNEL_DEFAULT == 4 && !(v4 >= 1 && v4 <= 3)))) kernel = 4;
     return kernel;
 }
 
@@ -856,6 +858,7 @@ static int wf_run_part(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t 
     while ((size_t)n_pixels * streams > 0xffffffffull) streams = (streams + 1) / 2;    /* slot indices are 32-bit */
     size_t n_slots = (size_t)n_pixels * streams;
     const int kernel = wf_pick_kernel<V>(c, true);
+    c->last_wf_kernel = kernel;
     int rc = wf_reserve(c, n_slots, kernel == 4);
     while (rc && streams > 1) {            /* no room for that many paths: halve, and remember */
         streams = (streams + 1) / 2;
@@ -1402,6 +1405,8 @@ extern "C" int rt_get_counters(rt_ctx* c, rt_counters* out)
     out->render_launches = c->launches;
     out->last_integrator = (uint32_t)c->last_integrator;
     out->wf_pools = (uint32_t)c->last_wf_pools;
+    out->wf_kernel = (uint32_t)c->last_wf_kernel;
+    out->reserved = 0u;
     out->wf_streams_found = c->wf_n_streams < 0 ? 0u : (uint32_t)c->wf_n_streams;
     return RT_OK;
 }

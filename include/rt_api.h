@@ -54,10 +54,13 @@ typedef struct rt_counters {
     double   last_render_ms;  /* HIP-event time of the most recent render kernel */
     uint32_t render_launches;
     uint32_t last_integrator; /* form the most recent render call ran in: RT_INTEGRATOR_MEGAKERNEL or _WAVEFRONT; 0 = none yet */
-    uint32_t wf_pools;        /* pools the most recent wavefront call ran as (3 by default; fewer when the context found fewer
-                                 streams that really run side by side: about -10 % in rate); 0 = no wavefront call yet */
-    uint32_t wf_streams_found;/* streams the context found to overlap when it looked (once, at its first wavefront call) */
-} rt_counters;                /* 48 bytes */
+    uint32_t wf_pools;        /* pools the most recent wavefront call ran as: 1 for the one-kernel form; 3 for the two-kernel forms
+                                 (fewer when the context found fewer streams that really run side by side); 0 = no wavefront call yet */
+    uint32_t wf_streams_found;/* streams the context found to overlap when it looked (once, at its first pooled wavefront call) */
+    uint32_t wf_kernel;       /* form of the most recent wavefront call: 4 = the whole path in one persistent kernel (default; it
+                                 runs as one "pool"), 1 / 2 / 3 = intersect + logic kernels (RT_WF_KERNEL); 0 = none yet */
+    uint32_t reserved;
+} rt_counters;                /* 56 bytes */
 
 const char* rt_last_error(void);
 

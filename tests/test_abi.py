@@ -33,7 +33,7 @@ def test_struct_layouts(binding):
     assert C.sizeof(binding.RtCamera) == 96          # same members as the reference Camera
     assert C.sizeof(binding.RtBvhNode) == 32
     assert C.sizeof(binding.RtHitRecord) == 52
-    assert C.sizeof(binding.RtCounters) == 48
+    assert C.sizeof(binding.RtCounters) == 56
     assert np.dtype(binding.HIT_DTYPE).itemsize == 52
 
 

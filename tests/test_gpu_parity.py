@@ -659,6 +659,38 @@ def test_wavefront_scheduling_switches_do_not_change_the_image(binding, gpu_ctx,
         assert torch.allclose(parts, firsts[1][0], rtol=2e-5, atol=1e-5)
 
 
+def test_wavefront_forms_give_the_same_image(binding, gpu_ctx, monkeypatch):
+    """The wavefront integrator has four forms (RT_WF_KERNEL): the default keeps a path in its lane from the camera to
+    the end (one persistent kernel, rt_wavefront4.h); 1, 2 and 3 keep the path state in HBM and alternate an intersect
+    kernel (the first design, staged rays + queued leaves, eight-wide quantised nodes) with the logic kernel.  Same slots,
+    same samples in the same order: the one-kernel form and the first design walk the same tree in the same order and
+    give the same bits; the other two may keep another winner where two primitives give the same t."""
+    import torch
+    W, H, spp = 160, 96, 12
+    for name, param in (("tri_mesh", 3000), ("final", 8), ("cornell_cluster", 0)):
+        sc = binding.Scene(name, W, H, param)
+        gpu_ctx.upload(sc)
+        images, rays = {}, {}
+        for kernel in (None, "1", "2", "3"):
+            if kernel is None:
+                monkeypatch.delenv("RT_WF_KERNEL", raising=False)
+            else:
+                monkeypatch.setenv("RT_WF_KERNEL", kernel)
+            gpu_ctx.reset_counters()
+            images[kernel] = render_gpu(gpu_ctx, binding, sc, W, H, 1, 1 + spp, 23, integrator="wavefront")
+            c = gpu_ctx.counters()
+            rays[kernel] = int(c.rays)
+            assert c.samples == W * H * spp and c.last_integrator == 2
+            assert c.wf_kernel == (4 if kernel is None else int(kernel))
+            assert c.wf_pools == 1 if kernel is None else c.wf_pools >= 1
+        monkeypatch.delenv("RT_WF_KERNEL", raising=False)
+        assert float(images[None].sum()) > 0
+        assert torch.equal(images[None], images["1"]) and rays[None] == rays["1"], name
+        for kernel in ("2", "3"):
+            differ = (images[kernel].view(-1, 3) != images[None].view(-1, 3)).any(dim=1).float().mean().item()
+            assert differ <= 2e-3 and abs(rays[kernel] - rays[None]) <= 2e-3 * rays[None], (name, kernel, differ)
+
+
 def test_wavefront_failure_leaves_the_context_usable(binding, gpu_ctx, monkeypatch):
     """the wavefront loop's error exits (a queue that does not drain, a failing HIP call) wait for every pool's stream
     before returning: forced here with RT_WF_DEBUG_MAX_ITERS=0, after which the same context renders as if nothing
