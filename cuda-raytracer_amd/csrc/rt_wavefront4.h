@@ -284,7 +284,17 @@ __global__ __launch_bounds__(RT_BLOCK, wf4_waves(F)) void wf_path_kernel(DScene 
         const int lfirst = (~pleaf) >> 4, lcount = ((~pleaf) & 15) + 1;
         const float4* nsrc = reinterpret_cast<const float4*>(S.nodes4 + (interior ? ref : 0));
         const float4* src = reinterpret_cast<const float4*>(S.leafs + (prim_step ? lfirst + li : 0));
-        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0, q3 = q0;
+        /* the leaf row, loaded only by the lanes that take a primitive step.  The other lanes' copies must still be DEFINED
+         * (left undefined, the allocator spilled: final scene 3.72 -> 2.65 Grays/s in wf_intersect_kernel), which cost 16 zero
+         * moves per trip there; an empty asm that "writes" them defines them without an instruction (1M triangles +2.6 %,
+         * final scene and sphere cluster +0.4 / +1.9 %) */
+        float4 q0, q1, q2, q3;
+#ifdef WF4_ZERO_FILL
+        q0 = make_float4(0.f, 0.f, 0.f, 0.f); q1 = q0; q2 = q0; q3 = q0;
+#else
+        asm volatile("" : "=v"(q0.x), "=v"(q0.y), "=v"(q0.z), "=v"(q0.w), "=v"(q1.x), "=v"(q1.y), "=v"(q1.z), "=v"(q1.w));
+        asm volatile("" : "=v"(q2.x), "=v"(q2.y), "=v"(q2.z), "=v"(q2.w), "=v"(q3.x), "=v"(q3.y), "=v"(q3.z), "=v"(q3.w));
+#endif
         if (prim_step) { q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3]; }
 
         if (interior) {
@@ -307,6 +317,8 @@ __global__ __launch_bounds__(RT_BLOCK, wf4_waves(F)) void wf_path_kernel(DScene 
             if (ref == RT_REF_NONE) WF_POP(ref)
         }
         if (prim_step) {
+            /* (the compiler hoists the first uses of the row into the block of its loads, so the wave waits for the leaf row
+             * before it asks for its node row; keeping them here with an asm barrier measured +-0: the pipes are busy anyway) */
             const uint32_t head = __float_as_uint(q0.x);
             const int oi = __float_as_int(q0.z);
             const float f[13] = {q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
