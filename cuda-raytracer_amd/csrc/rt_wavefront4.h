@@ -240,7 +240,7 @@ __global__ __launch_bounds__(RT_BLOCK, wf4_waves(F)) void wf_path_kernel(DScene 
                 ++n_rays;
                 scan_program<(F & ~RT_F_BVH)>(S, W.prog, rw, tMin, best, &g, bounce, stack);
                 gidx = 0;
-                WF_NEXT_GROUP
+                mode = W.n_groups > 0 ? WF_ENTER : WF_NEED;      /* the batch enters its first group in the trip below, with whoever else waits */
             }
         }
 #ifdef RT_STAMPS_REFILL
