@@ -144,11 +144,12 @@ def primary_rays(flat, W, H):
     return np.concatenate([np.tile(org, (W * H, 1)), d.astype(f), np.full((W * H, 1), cam.time0, f)], axis=1).astype(f)
 
 
-@pytest.mark.parametrize("kernel", ["1", "2"])
+@pytest.mark.parametrize("kernel", ["1", "2", "3"])
 @pytest.mark.parametrize("name", ["tri_mesh", "final"])
 def test_wavefront_traversal_at_full_size_matches_reference(binding, oracle_mod, gpu_ctx, monkeypatch, name, kernel):
     """north_star criterion 1 for the traversal the target scenes are RENDERED with: the primary rays of the full-size
-    reference maps (1,000,000 triangles; 100 x 100 boxes) through both intersect kernels of the wavefront form.  t is
+    reference maps (1,000,000 triangles; 100 x 100 boxes) through the three intersect kernels of the wavefront form (the
+    one-kernel form walks with the first one's step code).  t is
     bit-equal everywhere; an id may differ from the reference's flat list only at an identical t (the tie rules differ:
     first in list order there, lowest word in the mailbox / first met here), and then the megakernel's traversal, a
     third order, reports that same t as well."""
@@ -401,6 +402,23 @@ def test_wavefront_at_full_size(binding, gpu_ctx):
     assert differ <= 2e-5, differ
     auto = render_gpu(gpu_ctx, binding, sc, W, H, 0, 1, 9, integrator="auto")
     assert gpu_ctx.counters().last_integrator == 2 and torch.equal(auto, w1)     # a big BVH: auto = wavefront
+    # ... and that the rays which part ways do so at ties only is checked on the traversals themselves: the primary rays of
+    # a quarter-size frame and three bounce rays from every hit (about 1.3 M rays, most of them starting ON a triangle)
+    # through both trees.  Every ray: same hit flag, bit-equal t; a different id only at that identical t, and rarely.
+    rays = primary_rays(sc.flat, W // 2, H // 2)
+    first = gpu_trace(gpu_ctx, rays)
+    h = first["hit"] == 1
+    rng = np.random.default_rng(5)
+    origin = np.repeat(first["p"][h], 3, axis=0)
+    direction = rng.standard_normal(origin.shape).astype(np.float32)
+    bounce = np.concatenate([origin, direction, np.zeros((len(origin), 1), np.float32)], axis=1).astype(np.float32)
+    for batch in (rays, bounce):
+        two, four = gpu_trace(gpu_ctx, batch), gpu_trace(gpu_ctx, batch, via="wavefront")
+        assert np.array_equal(two["hit"], four["hit"])
+        hh = two["hit"] == 1
+        assert np.array_equal(two["t"][hh], four["t"][hh]), "the two trees give another t somewhere"
+        assert (two["prim"][hh] != four["prim"][hh]).mean() < 1e-3
+    assert h.mean() > 0.3 and len(bounce) > 500000
 
 
 def test_smoke_and_final_at_full_size(binding, gpu_ctx):

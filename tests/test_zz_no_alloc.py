@@ -72,3 +72,42 @@ def test_noalloc_limits(binding, gpu_ctx):
     with pytest.raises(binding.RtError):
         fresh.render_accumulate_noalloc(acc, W, H, 0, 1, 1, 100, 0)              # no scene
     fresh.close()
+
+
+def test_noalloc_under_graph_capture(binding):
+    """the callers the entry point is for include code under HIP graph capture: the call is captured on the context's
+    stream (nothing runs), the graph is instantiated and replayed twice, and the buffer then holds what two allocating
+    calls onto one buffer leave, bit for bit"""
+    import torch
+    W, H, s0, s1 = 96, 80, 0, 300                      # three runs: the scratch is in use
+    stream = torch.cuda.Stream()
+    ctx = binding.Context(0, stream.cuda_stream)
+    try:
+        sc = binding.Scene("cornell", W, H)
+        ctx.upload(sc)
+        ref = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
+        got = torch.zeros_like(ref)
+        torch.cuda.synchronize()
+        ctx.set_integrator(binding.RT_INTEGRATOR_MEGAKERNEL)
+        ctx.render_accumulate(ref, W, H, s0, s1, 11, 100, sc.background)
+        ctx.set_integrator(binding.RT_INTEGRATOR_AUTO)
+        ctx.render_accumulate_noalloc(got, W, H, s0, s1, 11, 100, sc.background)     # eager once: modules loaded before the capture
+        ctx.synchronize()
+        assert torch.equal(got, ref)
+        got.zero_()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            ctx.render_accumulate_noalloc(got, W, H, s0, s1, 11, 100, sc.background)
+        torch.cuda.synchronize()
+        assert float(got.abs().sum()) == 0.0           # captured, not run
+        graph.replay()
+        graph.replay()
+        torch.cuda.synchronize()
+        ctx.set_integrator(binding.RT_INTEGRATOR_MEGAKERNEL)
+        ctx.render_accumulate(ref, W, H, s0, s1, 11, 100, sc.background)             # the allocating call, a second time onto the same sums
+        ctx.set_integrator(binding.RT_INTEGRATOR_AUTO)
+        ctx.synchronize()
+        assert float(ref.sum()) > 0 and torch.equal(got, ref)
+    finally:
+        ctx.close()

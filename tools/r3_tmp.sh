@@ -1,10 +1,3 @@
 set -e
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/$1; mkdir -p $O
-run() { echo "== $*" | tee -a $O/rates.txt; env "$@" timeout -k 10 150 python3 tools/wf_rate.py $SCENE 2>/dev/null | tee -a $O/rates.txt; }
-for SCENE in "tri_mesh 1000000 1920 1080 128" "final 100 1920 1080 64" "cornell_cluster 0 1920 1080 64"; do
-  run A=0
-  run RT_AMD_LIB=tools/diag/librt_amd_eir.so
-  run A=1
-  run RT_AMD_LIB=tools/diag/librt_amd_eir.so
-done
+timeout -k 10 300 python -u -m pytest tests/test_zz_no_alloc.py -m gpu -x -q --timeout 180 --timeout-method thread 2>&1 | tail -25
