@@ -7,18 +7,23 @@
  * bench.py's cpu_baseline leg may load this library; the product
  * (cuda-raytracer_amd/) never does.
  *
- * Pinning (see DESIGN.md "Oracle"):
- *   - geometry  (Sphere, MovingSphere, XY/XZ/YZRect, FlipNormals, Box, Triangle,
- *     Translate, RotateY, HitableList), textures and materials are pinned against
- *     a host build of the reference's OWN headers (oracle/ref_driver.cpp ->
- *     oracle/_ref/libref.so, built where /root/reference exists) through the
- *     fixtures in tests/golden/ made by oracle/gen_golden.py.
- *   - Camera::generateRay (Camera.cuh:40-46), ConstantMedium::hit
+ * Pinning ("Oracle and parity"):
+ *   - PINNED by the reference compiled here with no stand-in of any kind
+ *     (oracle/ref_geom.cpp -> oracle/_ref/libref_geom.so, built where /root/reference
+ *     exists; the Makefile refuses the library if it names an RNG symbol): geometry
+ *     (Sphere, MovingSphere, XY/XZ/YZRect, FlipNormals, Box, Triangle, Translate,
+ *     RotateY, HitableList) and the textures, through the fixtures in tests/golden/
+ *     made by oracle/gen_golden.py.
+ *   - CROSS-CHECKED THROUGH A LABELLED STAND-IN, which pins nothing: the materials
+ *     (Material.cuh names curandState / curand_uniform from a toolkit the image
+ *     lacks; oracle/ref_shade.cpp -> oracle/_ref/libref_shade.so binds the two names
+ *     to rocRAND's Philox, and every fixture made from it says so in `produced_by`).
+ *   - PARITY UNPINNED: Camera::generateRay (Camera.cuh:40-46), ConstantMedium::hit
  *     (Volumes.cuh:26-49) and the integrator loops colour()/colourUnlit()
- *     (main.cu:48-100) are PARITY UNPINNED: Camera.cuh and Volumes.cuh include
- *     <curand_kernel.h> and main.cu needs the CUDA runtime, neither of which this
- *     image has, and the reference ships no tests or golden outputs.  They are
- *     restated line by line below with the reference line cited.
+ *     (main.cu:48-100): Camera.cuh and Volumes.cuh include <curand_kernel.h> and
+ *     main.cu needs the CUDA runtime, neither of which this image has, and the
+ *     reference ships no tests or golden outputs.  They are restated line by line
+ *     below with the reference line cited.
  *
  * Floating point: every expression keeps the reference's operand order and its
  * float/double promotions (noted where they matter).  Build with
