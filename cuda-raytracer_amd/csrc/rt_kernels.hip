@@ -899,17 +899,20 @@ static int wf_run_part(rt_ctx* c, int w, int h, int4 win, uint32_t s0, uint32_t 
             wf_count_samples_kernel<<<1, 1, 0, c->stream>>>(c->d_counters, (unsigned long long)n_pixels * (unsigned long long)(s1 - s0));
         } else {
             const size_t lds4 = lds + WF4_LDS_EXTRA_WORDS * sizeof(int);
+            /* four instantiations: black / sky background x one / several BVH groups in the world list (rt_wavefront4.h) */
+            using PathKernel = void (*)(DScene, WfState, int, int, uint32_t, uint32_t, uint32_t, uint32_t, int, unsigned long long*);
+            const bool mg = c->n_wf_groups != 1;
+            const PathKernel kern = background == RT_BG_BLACK ? (mg ? wf_path_kernel<V, RT_BG_BLACK, true> : wf_path_kernel<V, RT_BG_BLACK, false>)
+                                                              : (mg ? wf_path_kernel<V, RT_BG_SKY, true> : wf_path_kernel<V, RT_BG_SKY, false>);
             int per_cu = 0, cus = 0;
-            if (background == RT_BG_BLACK) { HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wf_path_kernel<V, RT_BG_BLACK>, RT_BLOCK, lds4)); }
-            else { HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wf_path_kernel<V, RT_BG_SKY>, RT_BLOCK, lds4)); }
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, RT_BLOCK, lds4));
             HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
             unsigned pblocks = (unsigned)(per_cu > 0 ? per_cu : 1) * (unsigned)(cus > 0 ? cus : 1);
             if (const char* e = std::getenv("RT_WF_IBLOCKS")) { const int v = std::atoi(e); if (v > 0) pblocks = (unsigned)v; }
             const unsigned all = (unsigned)((n_slots + RT_BLOCK - 1) / RT_BLOCK);
             if (pblocks > all) pblocks = all;
             if (std::getenv("RT_WF_DEBUG")) std::fprintf(stderr, "wf_run_part: path kernel, %u blocks (%d per CU), %zu B of LDS\n", pblocks, per_cu, lds4);
-            if (background == RT_BG_BLACK) wf_path_kernel<V, RT_BG_BLACK><<<dim3(pblocks), RT_BLOCK, lds4, c->stream>>>(c->ds, W, w, h, s0, s1, k0, k1, max_depth, c->d_counters);
-            else wf_path_kernel<V, RT_BG_SKY><<<dim3(pblocks), RT_BLOCK, lds4, c->stream>>>(c->ds, W, w, h, s0, s1, k0, k1, max_depth, c->d_counters);
+            kern<<<dim3(pblocks), RT_BLOCK, lds4, c->stream>>>(c->ds, W, w, h, s0, s1, k0, k1, max_depth, c->d_counters);
         }
         HIPCHK(hipGetLastError());
         wf_finalize_kernel<<<dim3((n_pixels + RT_BLOCK - 1) / RT_BLOCK), RT_BLOCK, 0, c->stream>>>(W, accum);

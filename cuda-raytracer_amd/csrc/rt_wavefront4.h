@@ -31,6 +31,10 @@
 #define WF4_TRI_WAVES 5
 #endif
 constexpr int wf4_waves(uint32_t F) { return (F & ~(RT_F_BVH | RT_F_TRI | RT_F_PLANAR)) == 0 ? WF4_TRI_WAVES : WF4_GENERAL_WAVES; }
+#ifndef WF4_INNER_LOOP_TRI
+#define WF4_INNER_LOOP_TRI false
+#endif
+constexpr bool wf4_inner_loop(uint32_t F) { return (F & ~(RT_F_BVH | RT_F_TRI | RT_F_PLANAR)) == 0 ? WF4_INNER_LOOP_TRI : true; }
 #ifndef WF4_ENTER_BATCH
 #define WF4_ENTER_BATCH 16      /* lanes waiting to enter their next BVH group that make the entry worth running */
 #endif
@@ -40,7 +44,10 @@ constexpr int wf4_waves(uint32_t F) { return (F & ~(RT_F_BVH | RT_F_TRI | RT_F_P
 #endif
 #define WF4_LDS_EXTRA_WORDS (7 * RT_BLOCK)      /* per lane: attenuation xyz, sum xyz; per wave: 64 ints for the ball draw */
 
-template <uint32_t F, int BG>
+/* MG: the world list holds more than one BVH group (the final scene: the box floor and the sphere cluster).  With a single
+ * group (the triangle mesh) a ray enters it in the refill and is finished when it leaves it: the trip loop then carries
+ * no entry block at all. */
+template <uint32_t F, int BG, bool MG>
 __global__ __launch_bounds__(RT_BLOCK, wf4_waves(F)) void wf_path_kernel(DScene S, WfState W, int Wd, int Hd, uint32_t s_begin, uint32_t s_end,
                                                                       uint32_t k0, uint32_t k1, int max_depth,
                                                                       unsigned long long* __restrict__ counters)
@@ -240,7 +247,8 @@ __global__ __launch_bounds__(RT_BLOCK, wf4_waves(F)) void wf_path_kernel(DScene 
                 ++n_rays;
                 scan_program<(F & ~RT_F_BVH)>(S, W.prog, rw, tMin, best, &g, bounce, stack);
                 gidx = 0;
-                mode = W.n_groups > 0 ? WF_ENTER : WF_NEED;      /* the batch enters its first group in the trip below, with whoever else waits */
+                if (MG) mode = WF_ENTER;      /* the batch enters its first group in the trip below, with whoever else waits */
+                else WF_NEXT_GROUP
             }
         }
 #ifdef RT_STAMPS_REFILL
@@ -251,12 +259,19 @@ __global__ __launch_bounds__(RT_BLOCK, wf4_waves(F)) void wf_path_kernel(DScene 
             continue;
         }
 
+        /* In the general variants the trips run as an inner loop of their own until the next batch is due: what only the
+         * refill reads (the frame, the sample range, the claim state, the camera) then lives OUTSIDE the loop that runs ten
+         * to twenty times as often, and the register allocator keeps its spills and reloads of those values out of the
+         * trips (final scene 4.44 -> 4.60 Grays/s at 1080p).  The triangle variant, squeezed into 96 registers for its fifth
+         * wave, does better as one flat loop (3.66 against 3.52). */
+        bool again;
+        do {
         /* ---- one trip: wf_intersect_kernel's, except that a ray which has finished a group does not enter the next one on
          * the spot.  Entering costs a wrapper chain and three divisions, about 70 instructions, and in a scene with two
          * groups two or three lanes finish their first group in every trip: run where it happens, the entry was a tenth of
          * the trip's instructions at 4 % of its lanes.  The lane waits (WF_ENTER) until enough lanes do, or the node steps
          * run low, like a postponed leaf. ---- */
-        {
+        if (MG) {
             const int n_enter = __popcll(__ballot(mode == WF_ENTER));
             if (n_enter > 0) {
                 const int n_walk = __popcll(__ballot(mode == WF_BVH && ref >= 0));
@@ -332,8 +347,17 @@ __global__ __launch_bounds__(RT_BLOCK, wf4_waves(F)) void wf_path_kernel(DScene 
         }
         if (in_bvh) {
             if (pleaf == RT_REF_NONE && ref < 0 && ref != RT_REF_NONE) { pleaf = ref; li = 0; WF_POP(ref) }
-            if (ref == RT_REF_NONE && pleaf == RT_REF_NONE) { ++gidx; mode = gidx < W.n_groups ? WF_ENTER : WF_NEED; }   /* the group is done */
+            if (ref == RT_REF_NONE && pleaf == RT_REF_NONE) { ++gidx; mode = MG && gidx < W.n_groups ? WF_ENTER : WF_NEED; }   /* the group is done */
         }
+            again = false;
+            if (wf4_inner_loop(F)) {
+                const bool idle2 = mode == WF_NEED;
+                const int n_idle2 = __popcll(__ballot(idle2));
+                const int n_work2 = __popcll(__ballot(idle2 && (live || !drained)));
+                const int thr2 = drained ? (__popcll(__ballot(live)) + 3) >> 2 : W.refill_min;
+                again = n_idle2 < 64 && !(n_work2 > 0 && n_work2 >= thr2);
+            }
+        } while (again);
     }
 #undef WF_NEXT_GROUP
 #undef WF_PUSH
