@@ -102,6 +102,9 @@ __global__ __launch_bounds__(RT_BLOCK, wf4_waves(F)) void wf_path_kernel(DScene 
     unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long dg_t0 = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef RT_STAMPS_RF3
+    unsigned long long rf3[5] = {0, 0, 0, 0, 0};      /* cycles in a refill's bounce / claims / plain records, lanes shaded, rays started */
+#endif
 
     while (true) {
         /* ---- refill: idle lanes run their bounce, ended paths take the next sample or a new slot, the batch enters the scene ---- */
@@ -180,6 +183,9 @@ __global__ __launch_bounds__(RT_BLOCK, wf4_waves(F)) void wf_path_kernel(DScene 
                     }
                 }
             }
+#ifdef RT_STAMPS_RF3
+            const unsigned long long rf_t1 = __builtin_amdgcn_s_memtime();
+#endif
             /* lanes without a path take the next slots of the wave's chunk of the work list (claims as in wf_intersect_kernel) */
             const unsigned long long want = __ballot(idle && !live);
             const int n_want = __popcll(want);
@@ -242,6 +248,9 @@ __global__ __launch_bounds__(RT_BLOCK, wf4_waves(F)) void wf_path_kernel(DScene 
                     }
                 }
             }
+#ifdef RT_STAMPS_RF3
+            const unsigned long long rf_t2 = __builtin_amdgcn_s_memtime();
+#endif
             if (want_ray) {
                 best.t = FLT_MAX; best.obj = -1; best.grp = -1; best.aux = 0;
                 ++n_rays;
@@ -250,6 +259,9 @@ __global__ __launch_bounds__(RT_BLOCK, wf4_waves(F)) void wf_path_kernel(DScene 
                 if (MG) mode = WF_ENTER;      /* the batch enters its first group in the trip below, with whoever else waits */
                 else WF_NEXT_GROUP
             }
+#ifdef RT_STAMPS_RF3
+            { const unsigned long long rf_t3 = __builtin_amdgcn_s_memtime(); rf3[0] += rf_t1 - rf_t0; rf3[1] += rf_t2 - rf_t1; rf3[2] += rf_t3 - rf_t2; rf3[3] += (unsigned long long)__popcll(shade_m); rf3[4] += (unsigned long long)__popcll(__ballot(want_ray)); }
+#endif
         }
 #ifdef RT_STAMPS_REFILL
         if (rf_on) { dg[4] += __builtin_amdgcn_s_memtime() - rf_t0; dg[5] += 1; }
@@ -367,6 +379,9 @@ __global__ __launch_bounds__(RT_BLOCK, wf4_waves(F)) void wf_path_kernel(DScene 
     if (lane == 0) atomicAdd(&counters[0], r);
     if (blockIdx.x == 0 && threadIdx.x == 0 && W.stream0 == 0)
         atomicAdd(&counters[1], (unsigned long long)W.n_pixels * (unsigned long long)(s_end - s_begin));
+#ifdef RT_STAMPS_RF3
+    if (lane == 0) for (int q = 0; q < 5; ++q) atomicAdd(&counters[16 + q], rf3[q]);
+#endif
 #ifdef RT_STAMPS
     dg[7] = __builtin_amdgcn_s_memtime() - dg_t0;
     if (lane == 0) for (int q = 0; q < 8; ++q) atomicAdd(&counters[4 + (q < 6 ? q : q + 4)], dg[q]);

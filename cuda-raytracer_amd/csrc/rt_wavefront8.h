@@ -5,8 +5,8 @@
  * batch at a time, leaves are not tested by the lane that meets them but queued per wave and tested 64 at a time, the
  * closest hit of a ray is a 64-bit mailbox word in LDS.  What changes is the node (rt_host.h DNode8, built by
  * rt_pack_bvh8): eight children behind 8-bit boxes in 80 bytes.  Counted on the 1M-triangle scene, the four-wide kernel
- * spends per ray 15 node rows of 7 sixteen-byte lane loads each (a CU's address unit takes about one such load per clock)
- * and 15 rounds of everything a trip costs beside the box tests; this one fetches fewer, smaller rows:
+ * spends per ray 19 node rows of 7 sixteen-byte lane loads each (a CU's address unit takes about one such load per clock)
+ * and 19 rounds of everything a trip costs beside the box tests; the idea was fewer, smaller rows:
  *  - one row = five lane loads, three of them the 48 bytes of boxes;
  *  - a child's planes are q * (2^e / d) + (p - o) / d: two constants per axis per node, then one byte-to-float conversion and
  *    one fused multiply-add per plane;
@@ -15,6 +15,10 @@
  *    NODE with children still to visit: child base | interior mask | hit mask in that order, 64 bits;
  *  - the items of the leaf children that were hit are a 16-bit mask over the node's own rows of the leaf table (row 16 node +
  *    slot, + 8 for a second item), queued in one go.
+ * MEASURED (profiles/r03_kernel_ab.txt, tools/stamps.py): it does not pay on that scene.  Per ray 19.2 eight-wide rows (the
+ * four-wide tree: 18.9) and 17.5 leaf rows (7.9): octant order visits children the sorted four-wide walk culls, and the
+ * mesh's boxes overlap whatever the width (tools/sim/bvh_sim.cpp).  1M triangles 2.40 Grays/s against 2.87 for the
+ * four-wide kernel in the same two-kernel form and 3.66 for the one-kernel form.  Opt-in: RT_WF_KERNEL=3.
  * Box culling never decides a result: the boxes are rounded outwards on the host (rt_flat_bvh8_check walks every item up
  * through all its ancestors' dequantised boxes), the rounding of the two constants is covered by the per-ray widening of
  * slab_axis8, and every primitive behind a box is tested with the reference's own arithmetic.

@@ -1,9 +1,11 @@
 set -e
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$1; mkdir -p $O
-run() { echo "== $*" | tee -a $O/rates.txt; env "$@" timeout -k 10 150 python3 tools/wf_rate.py $SCENE 2>/dev/null | tee -a $O/rates.txt; }
-for SCENE in "tri_mesh 1000000 1920 1080 256" "final 100 1920 1080 64" "cornell_cluster 0 1920 1080 64" "random_spheres 0 1920 1080 64"; do
-  run A=0
-  run RT_AMD_LIB=tools/diag/librt_amd_flat.so
-  run A=1
+for k in 4 1 2 3; do
+echo "== RT_WF_KERNEL=$k" | tee -a $O/stamps.txt
+RT_WF_KERNEL=$k timeout -k 10 200 python3 tools/stamps.py tri_mesh 1920 1080 8 1000000 2>/dev/null | tee -a $O/stamps.txt
+RT_WF_KERNEL=$k timeout -k 10 200 python3 tools/stamps.py final 1920 1080 16 100 2>/dev/null | tee -a $O/stamps.txt
+done
+for s in "tri_mesh 1920 1080 8 1000000" "final 1920 1080 16 100"; do
+RT_AMD_LIB=tools/diag/librt_amd_stampsrf.so RT_STAMPS_REFILL=1 RT_STAMPS_RF3=1 timeout -k 10 200 python3 tools/stamps.py $s 2>/dev/null | tee -a $O/stamps_refill.txt
 done

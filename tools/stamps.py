@@ -25,7 +25,10 @@ B.lib().rt_debug_stamps(ctx.handle, out)
 for q in range(6, 10):
     out[q] -= base[q]      # the device-global loop counters are not reset with the context's
 if os.environ.get("RT_INTEGRATOR") == "2" or (sc.flat.contents.n_bvh_nodes > 0 and os.environ.get("RT_INTEGRATOR") != "1"):
-    d = [float(out[q] - base[q]) for q in (0, 1, 2, 3, 4, 5, 10, 11)]      # the intersect kernel's eight counters
+    # the intersect kernel's eight counters live in the context's counter block, which reset_counters() has just zeroed: they
+    # are the measured call's alone (subtracting the warm-up's reading, as this script did until round 3, made every
+    # per-ray figure too small by warm-up samples / samples)
+    d = [float(out[q]) for q in (0, 1, 2, 3, 4, 5, 10, 11)]
     print("%s %dx%d@%d wavefront: %.1f ms, %.1f Mrays/s, rays %d" % (name, W, H, spp, c.last_render_ms, c.rays / c.last_render_ms / 1e3, c.rays))
     print("  intersect: %.1f trips per ray-lane (trips*64/rays), busy lanes/trip %.1f, node lanes %.1f, prim lanes %.1f"
           % (d[0] * 64 / c.rays, d[1] / d[0], d[2] / d[0], d[3] / d[0]))
@@ -36,6 +39,13 @@ if os.environ.get("RT_INTEGRATOR") == "2" or (sc.flat.contents.n_bvh_nodes > 0 a
         print("  trips with a node step %.3f (%.1f lanes each), with a primitive step %.3f (%.1f lanes each); stalled lanes/trip %.1f; cycles/trip %.0f"
               % (d[5] / d[0], d[2] / max(1.0, d[5]), d[6] / d[0], d[3] / max(1.0, d[6]), d[4] / d[0], d[7] / d[0]))
     print("  rows fetched per ray: %.2f four-wide nodes (128-B rows) + %.2f leaf primitives (64-B rows)" % (d[2] / c.rays, d[3] / c.rays))
+    if hasattr(B.lib(), "rt_debug_sections") and os.environ.get("RT_STAMPS_RF3"):      # variant built with -DRT_STAMPS -DRT_STAMPS_REFILL -DRT_STAMPS_RF3
+        sec = (C.c_ulonglong * 16)()
+        B.lib().rt_debug_sections.argtypes = [C.c_void_p, C.c_void_p]
+        B.lib().rt_debug_sections(ctx.handle, sec)
+        n_rf = max(1.0, d[5])
+        print("  a refill of the one-kernel form: bounce %.0f cycles (%.1f lanes), claims %.0f, plain records + group entry %.0f (%.1f rays started)"
+              % (sec[0] / n_rf, sec[3] / n_rf, sec[1] / n_rf, sec[2] / n_rf, sec[4] / n_rf))
     if hasattr(B.lib(), "rt_debug_sections") and os.environ.get("RT_WF_KERNEL", "1") == "2":
         sec = (C.c_ulonglong * 16)()
         B.lib().rt_debug_sections.argtypes = [C.c_void_p, C.c_void_p]
