@@ -10,8 +10,8 @@
  * registers and LDS from the camera to the end: when its ray's closest hit is known the lane is idle, and once enough
  * lanes of the wave are idle they run one bounce TOGETHER (rebuild, cooperative ball draw, scatter: wf_logic_one's body on
  * register state), paths that ended start the slot's next sample or take a fresh slot from the work list, and the batch
- * goes through the plain records and into the first BVH group exactly as a refill of wf_intersect_kernel does.  No path
- * state in HBM, no queues, no logic / scan / move launches, ONE drain per call.
+ * goes through the plain records of the world list as a refill of wf_intersect_kernel does and on into the first BVH group.
+ * No path state in HBM, no queues, no logic / scan / move launches, ONE drain per call.
  *
  * The work list is the slot index space itself (slot = stream * n_pixels + window pixel, claimed in chunks with the same
  * XCD-affine heads); a slot runs its samples s_begin + k, s_begin + k + K, ... one after the other and leaves their sum in
@@ -22,8 +22,9 @@
 #define RT_WAVEFRONT4_H
 #include "rt_wavefront.h"
 
-/* waves per SIMD: measured (1080p; 1M triangles x 256 spp / final scene x 64 spp, Grays/s) 3 waves 3.20 / 3.69, 4 waves 3.19 / 4.20,
- * 5 waves 3.51 / 3.92 -- the triangle variant fits 96 registers, the general ones spill there */
+/* waves per SIMD: measured when the kernel was first built (1080p; 1M triangles x 256 spp / final scene x 64 spp, Grays/s)
+ * 3 waves 3.20 / 3.69, 4 waves 3.19 / 4.20, 5 waves 3.51 / 3.92 -- the triangle variant lives with 96 registers (13 spilled),
+ * the general ones do not */
 #ifndef WF4_GENERAL_WAVES
 #define WF4_GENERAL_WAVES 4
 #endif
