@@ -104,7 +104,7 @@ __global__ __launch_bounds__(RT_BLOCK, wf4_waves(F)) void wf_path_kernel(DScene 
     const unsigned long long dg_t0 = __builtin_amdgcn_s_memtime();
 #endif
 #ifdef RT_STAMPS_RF3
-    unsigned long long rf3[5] = {0, 0, 0, 0, 0};      /* cycles in a refill's bounce / claims / plain records, lanes shaded, rays started */
+    unsigned long long rf3[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      /* cycles in a refill's bounce / claims / plain records, lanes shaded, rays started; lanes and batches per material kind */
 #endif
 
     while (true) {
@@ -123,6 +123,11 @@ __global__ __launch_bounds__(RT_BLOCK, wf4_waves(F)) void wf_path_kernel(DScene 
 #endif
         if (n_work > 0 && (n_work >= thr || n_busy == 0)) {
             bool want_ray = false;
+            /* a lane that starts a sample: the next one of its slot (a path ended in the bounce) or the first one of a slot
+             * it claims.  ONE camera-ray block serves both: it is a Philox block, the lens draw and the ray, a few hundred
+             * instructions that a handful of the batch's lanes run, and two copies of it ran in most refills */
+            bool starting = false;
+            uint32_t start_s = 0u;
             if (shade_m) {
                 /* one iteration of colour() / colourUnlit(), main.cu:53-70 / :77-98 — wf_logic_one on register state */
                 const bool active = idle && live;
@@ -135,6 +140,12 @@ __global__ __launch_bounds__(RT_BLOCK, wf4_waves(F)) void wf_path_kernel(DScene 
                     rebuild<F, false>(S, rw, best, .001f, rec);
                     mtype = S.mats[rec.material].type;
                 }
+#ifdef RT_STAMPS_RF3
+                for (int mt_ = 0; mt_ < 5; ++mt_) {      /* lanes of each material kind in this batch, batches that hold the kind */
+                    const int nm_ = __popcll(__ballot(hit && mtype == mt_));
+                    rf3[5 + mt_] += (unsigned long long)nm_; rf3[10 + mt_] += nm_ ? 1ull : 0ull;
+                }
+#endif
                 const bool need_ball = hit && mtype != RT_MAT_LIGHT && mtype != RT_MAT_GLASS;
                 const V3 ball = random_in_unit_sphere_wave(g, bounce, need_ball, ball_slots);
                 if (active) {
@@ -171,12 +182,7 @@ __global__ __launch_bounds__(RT_BLOCK, wf4_waves(F)) void wf_path_kernel(DScene 
                         const uint32_t next = g.sample + W.streams;
                         if (next < s_end && next > g.sample) {
                             pst[3 * RT_BLOCK] = sx; pst[4 * RT_BLOCK] = sy; pst[5 * RT_BLOCK] = sz;
-                            float4 o4, d4, a4;
-                            wf_start_sample<F>(S, W, slot, next, Wd, Hd, k0, k1, o4, d4, a4);
-                            rw.o = mk(o4.x, o4.y, o4.z); rw.time = o4.w; rw.d = mk(d4.x, d4.y, d4.z);
-                            g.sample = next; bounce = 0;
-                            pst[0] = 1.f; pst[RT_BLOCK] = 1.f; pst[2 * RT_BLOCK] = 1.f;
-                            want_ray = true;
+                            start_s = next; starting = true;      /* the slot's next sample: its camera ray is made below */
                         } else {
                             W.sum[slot] = make_float4(sx, sy, sz, 0.f);
                             live = false;
@@ -237,17 +243,21 @@ __global__ __launch_bounds__(RT_BLOCK, wf4_waves(F)) void wf_path_kernel(DScene 
                     const uint32_t e = base + rank;
                     if (e < chunk_end) {
                         slot = e;
-                        const uint32_t s = s_begin + W.stream0 + slot / W.n_pixels;      /* the slot's first sample (never more streams than samples) */
-                        float4 o4, d4, a4;
-                        wf_start_sample<F>(S, W, slot, s, Wd, Hd, k0, k1, o4, d4, a4);
-                        rw.o = mk(o4.x, o4.y, o4.z); rw.time = o4.w; rw.d = mk(d4.x, d4.y, d4.z);
-                        g.pixel = wf_frame_pixel(W, slot); g.sample = s; bounce = 0;
-                        pst[0] = 1.f; pst[RT_BLOCK] = 1.f; pst[2 * RT_BLOCK] = 1.f;
+                        start_s = s_begin + W.stream0 + slot / W.n_pixels;      /* the slot's first sample (never more streams than samples) */
+                        g.pixel = wf_frame_pixel(W, slot);
                         pst[3 * RT_BLOCK] = 0.f; pst[4 * RT_BLOCK] = 0.f; pst[5 * RT_BLOCK] = 0.f;
                         live = true;
-                        want_ray = true;
+                        starting = true;
                     }
                 }
+            }
+            if (starting) {
+                float4 o4, d4, a4;
+                wf_start_sample<F>(S, W, slot, start_s, Wd, Hd, k0, k1, o4, d4, a4);
+                rw.o = mk(o4.x, o4.y, o4.z); rw.time = o4.w; rw.d = mk(d4.x, d4.y, d4.z);
+                g.sample = start_s; bounce = 0;
+                pst[0] = 1.f; pst[RT_BLOCK] = 1.f; pst[2 * RT_BLOCK] = 1.f;
+                want_ray = true;
             }
 #ifdef RT_STAMPS_RF3
             const unsigned long long rf_t2 = __builtin_amdgcn_s_memtime();
@@ -381,7 +391,7 @@ __global__ __launch_bounds__(RT_BLOCK, wf4_waves(F)) void wf_path_kernel(DScene 
     if (blockIdx.x == 0 && threadIdx.x == 0 && W.stream0 == 0)
         atomicAdd(&counters[1], (unsigned long long)W.n_pixels * (unsigned long long)(s_end - s_begin));
 #ifdef RT_STAMPS_RF3
-    if (lane == 0) for (int q = 0; q < 5; ++q) atomicAdd(&counters[16 + q], rf3[q]);
+    if (lane == 0) for (int q = 0; q < 15; ++q) atomicAdd(&counters[16 + q], rf3[q]);
 #endif
 #ifdef RT_STAMPS
     dg[7] = __builtin_amdgcn_s_memtime() - dg_t0;

@@ -46,6 +46,8 @@ if os.environ.get("RT_INTEGRATOR") == "2" or (sc.flat.contents.n_bvh_nodes > 0 a
         n_rf = max(1.0, d[5])
         print("  a refill of the one-kernel form: bounce %.0f cycles (%.1f lanes), claims %.0f, plain records + group entry %.0f (%.1f rays started)"
               % (sec[0] / n_rf, sec[3] / n_rf, sec[1] / n_rf, sec[2] / n_rf, sec[4] / n_rf))
+        kinds = ["lambert", "metal", "glass", "light", "isotropic"]
+        print("  material kinds in a batch: " + ", ".join("%s in %.0f %% of the batches (%.1f lanes when present)" % (k, 100.0 * sec[10 + i] / n_rf, sec[5 + i] / max(1.0, sec[10 + i])) for i, k in enumerate(kinds)))
     if hasattr(B.lib(), "rt_debug_sections") and os.environ.get("RT_WF_KERNEL", "1") == "2":
         sec = (C.c_ulonglong * 16)()
         B.lib().rt_debug_sections.argtypes = [C.c_void_p, C.c_void_p]
