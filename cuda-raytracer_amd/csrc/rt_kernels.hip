@@ -41,11 +41,14 @@
 #ifndef RT_WF_AUTO_ITEMS
 #define RT_WF_AUTO_ITEMS 128          /* BVH items from which RT_INTEGRATOR_AUTO takes the wavefront form */
 #endif
-/* Paths the wavefront integrator keeps in flight (88 B of HBM each: 11.3 GB at this default).  Measured on the
- * 1M-triangle scene at 1080p x 128 spp / the final scene at 4K x 128 spp, Grays/s: 8 M slots 1.38 / 1.52,
- * 16 M 1.52 / 1.64, 32 M 1.62 / 1.75, 64 M 1.75 / 1.83, 128 M 1.81 / 1.89, 256 M 1.84 / 1.94: every launch ends with a
- * drain in which the waves wait for their last rays, and the more rays a launch carries the less that costs.
- * The environment variable RT_WF_SLOTS overrides it; an allocation that fails is retried at half the size. */
+/* Slots (pixel x sample stream) a wavefront call is cut into; a slot's samples run one after the other.  In the one-kernel
+ * form (rt_wavefront4.h) a slot costs 16 B of HBM (2 GB at this default) and its samples run in ONE lane, so when the
+ * work list is empty the call waits for the longest slot: measured at 1080p, 1M triangles x 256 spp / final scene x 64 spp,
+ * Grays/s: 8 M slots 3.24 / 2.60, 33 M 3.50 / 3.73, 128 M 3.54 / 4.24, 260 M 3.53 / 4.25.  In the two-kernel forms a slot is a
+ * path in flight (88 B each: 11.3 GB) and every launch ends with a drain in which the waves wait for their last rays, the
+ * more rays a launch carries the less that costs (round 1, same two scenes at 128 spp: 8 M 1.38 / 1.52, 32 M 1.62 / 1.75,
+ * 128 M 1.81 / 1.89, 256 M 1.84 / 1.94).  The environment variable RT_WF_SLOTS overrides it; an allocation that fails is
+ * retried at half the size. */
 #ifndef RT_WF_SLOTS
 #define RT_WF_SLOTS (1u << 27)
 #endif
@@ -1228,9 +1231,10 @@ extern "C" int rt_render_accumulate_window(rt_ctx* c, int w, int h, int x0, int 
     EVCHK(hipEventCreate(&e1));
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     EVCHK(hipEventRecord(e0, c->stream));
-    /* auto: the wavefront form pays off as soon as a BVH is traversed.  Measured at 1920x1080 (tools/compare_integrators.py),
-     * wavefront / megakernel: 1M triangles 1.97, 200 k 1.61, 20 k 1.21; final scene (11 k or 1.4 k items) 2.29-2.41; Cornell +
-     * 1000-sphere cluster 1.51; 488 spheres in a world BVH 1.17; 16 boxes 0.48; no BVH at all (Cornell) 0.31. */
+    /* auto: the wavefront form pays off as soon as a BVH is traversed.  Measured at 1920x1080 x 32 spp (tools/compare_integrators.py),
+     * wavefront (one kernel, round 3) / megakernel: 1M triangles 3.18, 200 k 2.58, 20 k 1.82; final scene with 11 k / 1.4 k items
+     * 3.27 / 3.55; Cornell + 1000-sphere cluster 2.43; 488 spheres in a world BVH 1.95; 16 boxes 1.02; no BVH at all (Cornell,
+     * Cornell smoke) 0.92 / 0.88.  (Two-kernel form, round 2: 1.97, 1.61, 1.21; 2.29-2.41; 1.51; 1.17; 0.48; 0.31.) */
     const bool big = c->n_bvh_items >= RT_WF_AUTO_ITEMS;
     const bool wavefront = c->integrator == RT_INTEGRATOR_WAVEFRONT || (c->integrator == RT_INTEGRATOR_AUTO && big && c->stack4 <= WF_LDS_STACK + WF_OVF_STACK);
     c->last_integrator = wavefront ? RT_INTEGRATOR_WAVEFRONT : RT_INTEGRATOR_MEGAKERNEL;
