@@ -99,9 +99,10 @@ int  rt_scene_upload(rt_ctx* c, const rt_flat_scene* flat);
 /* ---- closest hit (the body of colour()'s loop, main.cu:56; HitableList::hit) ---- */
 /* n rays of 7 floats (origin, direction, time); media are ignored (no RNG in a bare query) */
 int  rt_trace_rays(rt_ctx* c, int n, const float* rays7_dev, float tmin, float tmax, rt_hit_record* out_dev);
-/* The same query through the traversal the WAVEFRONT form of the integrator renders with (its persistent intersect
- * kernel over a queue of the n rays: four-wide nodes, staged rays, queued leaves) instead of the megakernel's, so that
- * its hits can be held against the reference's vectors directly and not only through whole renders.  tmin = .001f and
+/* The same query through the traversal the WAVEFRONT form of the integrator renders with (the step interpreter over the
+ * four-wide trees, run by the persistent intersect kernel over a queue of the n rays; RT_WF_KERNEL=2 / 3 select the
+ * leaf-queue and the eight-wide intersect kernels) instead of the megakernel's, so that its hits can be held against the
+ * reference's vectors directly and not only through whole renders.  tmin = .001f and
  * tmax = FLT_MAX are the integrator's own (main.cu:56) and fixed; media are ignored here too.  Uses the context's
  * wavefront state: not to be overlapped with a render on the same context. */
 int  rt_trace_rays_wavefront(rt_ctx* c, int n, const float* rays7_dev, rt_hit_record* out_dev);
@@ -161,11 +162,14 @@ int  rt_render_accumulate_noalloc(rt_ctx* c, int width, int height, uint32_t sam
  * kernel is one monolithic per-pixel loop, main.cu:125-198):
  *   RT_INTEGRATOR_MEGAKERNEL  one kernel, a path stays in its lane from camera to termination and the lane
  *                             starts its pixel's next sample the moment the path ends; asynchronous.
- *   RT_INTEGRATOR_WAVEFRONT   path state in HBM, a persistent intersect kernel fed from a ray queue and a
- *                             shading kernel alternate until every path has ended; the call returns after
- *                             the last launch has been queued but blocks the host while the loop runs.
- *   RT_INTEGRATOR_AUTO        (default) wavefront for scenes whose BVHs hold at least 128 items (measured break-even:
- *                             it is 1.6x faster on 488 spheres, 0.6x on 16 boxes); megakernel otherwise.
+ *   RT_INTEGRATOR_WAVEFRONT   one persistent kernel whose every lane advances ITS ray through the BVHs by one step per
+ *                             trip (a four-wide node, or one leaf primitive) and is handed its path's next ray, or the
+ *                             next path, as soon as enough lanes of its wave are free (csrc/rt_wavefront4.h);
+ *                             asynchronous.  RT_WF_KERNEL=1..3 in the environment select the older forms instead (path
+ *                             state in HBM, an intersect kernel and a shading kernel alternating over a ray queue),
+ *                             which block the host while their loop runs.
+ *   RT_INTEGRATOR_AUTO        (default) wavefront for scenes whose BVHs hold at least 128 items (measured: 1.95x the
+ *                             megakernel on 488 spheres, 1.02x on 16 boxes, 0.92x on the Cornell box); megakernel otherwise.
  * Both trace the same path for the same (seed, pixel, sample). */
 enum rt_integrator { RT_INTEGRATOR_AUTO = 0, RT_INTEGRATOR_MEGAKERNEL = 1, RT_INTEGRATOR_WAVEFRONT = 2 };
 int  rt_ctx_set_integrator(rt_ctx* c, int mode);
