@@ -77,6 +77,17 @@ def self_launch(n):
     return p.wait()
 
 
+def sources_sha16():
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "cuda-raytracer_amd", "csrc", "*"))):
+        if f.endswith((".h", ".hip", ".cpp")):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def flops_per_ray(st):
     """algorithmic fp32 ops per ray from the instrumented CPU traversal of the same workload"""
     rays = max(1, st.rays)
@@ -360,6 +371,9 @@ def main():
                 # chip's issue slots that carried a live lane (= VALU-busy share x lane efficiency)
                 roof["issue_ceiling_frac"] = pm["lane_instructions_per_ray"] * rays_per_launch / kernel_s / (N_CUS * 4 * 16 * CLOCK_GHZ * 1e9)
             roof["pmc"] = {k: v for k, v in pm.items() if k not in ("traffic_bytes", "traffic_uncorrected_bytes", "rays")}
+            # do the committed counter passes describe the sources this library was built from?  (tools/make_profiles.py hashes
+            # cuda-raytracer_amd/csrc at the time of the passes; false = re-run tools/prof_round.sh)
+            roof["pmc_matches_sources"] = pm.get("sources_sha16") == sources_sha16() if pm.get("sources_sha16") else None
         out["roofline"] = roof
         return out
 

@@ -24,6 +24,18 @@ try:
         commit += "+uncommitted"
 except Exception:
     commit = "unknown"
+def sources_sha16():
+    """hash of the device and host sources the library is built from: bench.py recomputes it and says whether the counter
+    passes describe the code it is timing (roofline.pmc_matches_sources)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "cuda-raytracer_amd", "csrc", "*"))):
+        if f.endswith((".h", ".hip", ".cpp")):
+            h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+sources = sources_sha16()
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -116,7 +128,7 @@ for wl, key in (("cornell", None), ("smoke", None)):
     if not rays or not g(wl, "render_kernel", "FETCH_SIZE"):
         continue
     traffic = (2.0 * g(wl, "render_kernel", "FETCH_SIZE") + g(wl, "render_kernel", "WRITE_SIZE")) * 1024.0
-    summary[workload] = dict(derived(wl, "render_kernel"), kernel="render_kernel", source=tag, commit=commit, counted_on=workload, rays=rays,
+    summary[workload] = dict(derived(wl, "render_kernel"), kernel="render_kernel", source=tag, commit=commit, sources_sha16=sources, counted_on=workload, rays=rays,
                              traffic_bytes=traffic, traffic_bytes_per_ray=traffic / rays,
                              # active lanes x VALU instructions (SQ_THREAD_CYCLES_VALU counts lanes x quad-cycles): bench.py divides by
                              # its own kernel time and by 1024 SIMDs x 16 lanes x clock -> issue_ceiling_frac
@@ -134,7 +146,7 @@ for wl, stamps, stands_for in (("tri", "stamps_tri.txt", "tri_mesh"), ("final", 
     fetch_isect = g(wl, main, "FETCH_SIZE") * 1024.0
     write = sum(v for (w, k, c), v in allsum.items() if w == wl and c == "WRITE_SIZE") * 1024.0
     traffic = fetch - fetch_isect + fetch_isect * gather_fix + write
-    summary[workload] = dict(derived(wl, main), kernel=main, source=tag, commit=commit, counted_on=workload,
+    summary[workload] = dict(derived(wl, main), kernel=main, source=tag, commit=commit, sources_sha16=sources, counted_on=workload,
         stands_for=stands_for, rays=rays,
         # path state: none in the one-kernel form (a 16-B sum per slot at its end); in the two-kernel form ray_o + ray_d read by
         # the refill and hit written, three 16-B pieces per ray with four neighbouring rays sharing each 64-B line
