@@ -28,6 +28,7 @@ static std::vector<DNode4> n4;
 static std::vector<DNode8> n8;
 static std::vector<DLeaf> l8;
 static std::vector<DObj> leafs;          /* item order */
+static std::vector<int> level_of;        /* depth of each four-wide node, root = 0 */
 
 static bool tri_hit(const float* f, const Ray& r, float tmin, float tmax, float& t)
 {
@@ -64,12 +65,14 @@ static bool slab(const float* lo, const float* hi, const Ray& r, const float* id
 }
 struct Count { double nodes = 0, prims = 0, rays = 0, hits = 0; };
 
+static double visits_below[4] = {0, 0, 0, 0};      /* four-wide node visits in the top 1, 2, 3, 4 levels of the tree (1, 5, 21, 85 nodes) */
 static float walk4(int root, const Ray& r, Count& c)
 {
     float id[3] = {1.f / r.d[0], 1.f / r.d[1], 1.f / r.d[2]}, best = FLT_MAX;
     std::vector<int> st{root};
     while (!st.empty()) {
         int ref = st.back(); st.pop_back();
+        if (ref >= 0 && ref != RT_REF_NONE) for (int q = 0; q < 4; ++q) if (level_of[(size_t)ref] <= q) visits_below[q] += 1;
         if (ref == RT_REF_NONE) continue;
         if (ref < 0) {
             uint32_t first = (uint32_t)(~ref) >> 4, cnt = ((uint32_t)(~ref) & 15u) + 1u;
@@ -162,6 +165,16 @@ int main(int argc, char** argv)
     for (int i = 0; i < F->n_objects; ++i) if (F->objects[i].type == RT_OBJ_GROUP && F->objects[i].bvh_root >= 0) group = i;
     const int root4 = objs[(size_t)group].pad[0], root8 = objs[(size_t)group].pad[1];
     std::printf("tri_mesh %d: nodes4 %zu (depth %d), nodes8 %zu (depth %d)\n", n_tri, n4.size(), d4, n8.size(), d8);
+    level_of.assign(n4.size(), 99);
+    {
+        std::vector<std::pair<int, int>> st{{root4, 0}};
+        while (!st.empty()) {
+            auto [ni, lv] = st.back(); st.pop_back();
+            if (ni < 0 || ni == RT_REF_NONE) continue;
+            level_of[(size_t)ni] = lv;
+            for (int k = 0; k < 4; ++k) st.push_back({n4[(size_t)ni].ref[k], lv + 1});
+        }
+    }
     /* rays */
     std::vector<Ray> rays;
     const rt_camera& cam = F->camera;
@@ -182,6 +195,7 @@ int main(int argc, char** argv)
     }
     auto report = [&](const char* name, Count c) { std::printf("%-44s nodes/ray %6.2f  prims/ray %6.2f\n", name, c.nodes / rays.size(), c.prims / rays.size()); };
     Count a, b, c, d1, d3, d6, e0, e3; double diff = 0;
+    for (double& v : visits_below) v = 0;      /* the pass that made the bounce rays does not count */
     for (const Ray& r : rays) {
         const float ta = walk4(root4, r, a), tb = walk8(root8, r, b, 0, 0);
         walk8(root8, r, c, 1, 0); walk8(root8, r, e0, 2, 0); walk8(root8, r, e3, 2, 3); walk8(root8, r, d1, 0, 1); walk8(root8, r, d3, 0, 3); walk8(root8, r, d6, 0, 6);
@@ -189,6 +203,8 @@ int main(int argc, char** argv)
     }
     std::printf("%zu rays, %g with another t between the two trees\n", rays.size(), diff);
     report("A four-wide, sorted, leaves at once", a);
+    std::printf("   of those, in the top 1 / 2 / 3 / 4 levels (1 / 5 / 21 / 85 nodes): %.2f / %.2f / %.2f / %.2f per ray\n",
+                visits_below[0] / rays.size(), visits_below[1] / rays.size(), visits_below[2] / rays.size(), visits_below[3] / rays.size());
     report("B eight-wide, octant order, leaves at once", b);
     report("C eight-wide, sorted, leaves at once", c);
     report("E eight-wide, corner-projection order, at once", e0);
