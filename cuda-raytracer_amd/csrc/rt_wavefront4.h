@@ -24,7 +24,9 @@
 
 /* waves per SIMD: measured when the kernel was first built (1080p; 1M triangles x 256 spp / final scene x 64 spp, Grays/s)
  * 3 waves 3.20 / 3.69, 4 waves 3.19 / 4.20, 5 waves 3.51 / 3.92 -- the triangle variant lives with 96 registers (13 spilled),
- * the general ones do not */
+ * the general ones do not.  Again at the end of round 3 (tools/lib_ab.sh): general variants at 3 / 4 / 5 waves, final scene
+ * 4.08 / 4.57 / 4.42, Cornell + sphere cluster 5.75 / 6.52 / 4.51; triangle variant at 4 waves with the inner trip loop 3.58
+ * against 3.70 as it is */
 #ifndef WF4_GENERAL_WAVES
 #define WF4_GENERAL_WAVES 4
 #endif
