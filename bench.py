@@ -186,7 +186,15 @@ def main():
     dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # RT_BENCH_FORCE_DIST=1: at N = 1 too, create the process group and run every collective of the N > 1 flow (reduce onto
+    # rank 0, the two all-reduces, the barriers) -- with one rank they move nothing, but the RCCL calls, their ordering
+    # against the render stream and the teardown execute on the hardware at hand (tests/test_z_bench_gpu.py)
+    use_dist = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        if "MASTER_ADDR" not in os.environ:       # forced at N = 1 without a launcher
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1")
         if backend == "gloo":
             dist.init_process_group("gloo")
         else:
@@ -233,14 +241,14 @@ def main():
             accum.zero_()
             s0, s1 = step_sample_range(scaling, k, rank, world, spp)
             ctx.render_accumulate(accum, W, H, s0, s1, 419, 100, background)
-            if world > 1:
+            if use_dist:
                 coll(dist.reduce, accum, dst=0, op=dist.ReduceOp.SUM)
             if rank == 0:
                 rgb = ctx.resolve(accum, W, H, spp_total, gamma=True)
 
         def fence():
             torch.cuda.synchronize(dev)
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -258,7 +266,7 @@ def main():
 
         tot = torch.tensor([float(c.rays), float(c.samples)], dtype=torch.float64, device=dev)
         tmax = torch.tensor([dt, c.render_ms / max(1, c.render_launches)], dtype=torch.float64, device=dev)
-        if world > 1:
+        if use_dist:
             coll(dist.all_reduce, tot, op=dist.ReduceOp.SUM)
             coll(dist.all_reduce, tmax, op=dist.ReduceOp.MAX)
         rays, samples = tot.tolist()
@@ -278,7 +286,7 @@ def main():
                        "background": "sky" if background else "black", "bvh": has_bvh,
                        "integrator": "wavefront" if wavefront else "megakernel",
                        "wf_kernel": int(c.wf_kernel) if wavefront else None, "wf_pools": int(c.wf_pools) if wavefront else None,
-                       "parallelism": ("spp-shard x%d (%s) + %s" % (world, scaling, "RCCL reduce" if backend == "nccl" else "gloo reduce (REHEARSAL, ranks share GPUs)")) if world > 1 else "single GPU"},
+                       "parallelism": ("spp-shard x%d (%s) + %s" % (world, scaling, "RCCL reduce" if backend == "nccl" else "gloo reduce (REHEARSAL, ranks share GPUs)")) if world > 1 else ("single GPU" + (" (collectives executed with one rank, %s)" % backend if use_dist else ""))},
             "samples_per_s": samples / dt, "rays_per_sample": rays / max(1.0, samples),
             "image_mean": mean_rgb, "image_finite": finite,
         }
@@ -398,7 +406,7 @@ def main():
             out["also"] = also
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -76,6 +76,17 @@ class Oracle(_Common):
             raise RuntimeError("%s missing: run `make -C oracle`" % path)
         super().__init__(C.CDLL(path), "rto_")
 
+    def object_hit_addressed(self, flat, obj, rays, tmin, tmax, seed, pixel_sample_bounce):
+        """one object's hit() with the addressed draws of (seed, pixel, sample, bounce): media take their draw"""
+        rays = _f32(rays)
+        psb = np.ascontiguousarray(pixel_sample_bounce, dtype=np.uint32)
+        out = np.zeros(rays.shape[0], dtype=HIT_DTYPE)
+        fn = self.lib.rto_object_hit_addressed
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p]
+        fn.restype = None
+        fn(C.cast(flat, C.c_void_p), obj, rays.shape[0], _ptr(rays), tmin, tmax, seed, _ptr(psb), _ptr(out))
+        return out
+
     def scatter(self, flat, mat, ray_in, rec_in, xi):
         """xi[n, stride]: scripted uniforms, consumed per call in the order the reference draws them"""
         ray_in, rec_in, xi = _f32(ray_in), _f32(rec_in), _f32(xi)

@@ -23,7 +23,9 @@
  *     (main.cu:48-100): Camera.cuh and Volumes.cuh include <curand_kernel.h> and
  *     main.cu needs the CUDA runtime, neither of which this image has, and the
  *     reference ships no tests or golden outputs.  They are restated line by line
- *     below with the reference line cited.
+ *     below with the reference line cited.  generateRay and ConstantMedium::hit are
+ *     restated a second time in numpy (tests/test_cross_restatement.py) and the two
+ *     readings must agree bit for bit: a guard against a typo, not a pin.
  *
  * Floating point: every expression keeps the reference's operand order and its
  * float/double promotions (noted where they matter).  Build with
@@ -723,6 +725,25 @@ void rto_object_hit(const rt_flat_scene* s, int object, int n, const float* rays
     for (int i = 0; i < n; ++i) {
         const float* q = rays + 7 * (size_t)i;
         Ray r = {v3(q[0], q[1], q[2]), v3(q[3], q[4], q[5]), q[6]};
+        Hit rec;
+        memset(&rec, 0, sizeof rec);
+        int h = hit_object(&c, object, &r, tmin, tmax, &rec);
+        fill_out(&out[i], h, &rec);
+    }
+}
+
+/* one object's hit() with the path tracer's ADDRESSED draws for (seed, pixel, sample, bounce): unlike rto_object_hit
+ * a ConstantMedium takes its free-flight draw (Volumes.cuh:40).  Test hook of tests/test_cross_restatement.py. */
+void rto_object_hit_addressed(const rt_flat_scene* s, int object, int n, const float* rays, float tmin, float tmax,
+                              uint64_t seed, const uint32_t* pixel_sample_bounce, rto_hit* out)
+{
+    for (int i = 0; i < n; ++i) {
+        const float* q = rays + 7 * (size_t)i;
+        Ray r = {v3(q[0], q[1], q[2]), v3(q[3], q[4], q[5]), q[6]};
+        Rng g;
+        rng_init(&g, seed, pixel_sample_bounce[3 * i], pixel_sample_bounce[3 * i + 1], NULL);
+        g.bounce = pixel_sample_bounce[3 * i + 2];
+        Ctx c = {s, &g, 0, NULL};
         Hit rec;
         memset(&rec, 0, sizeof rec);
         int h = hit_object(&c, object, &r, tmin, tmax, &rec);

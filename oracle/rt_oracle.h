@@ -49,6 +49,9 @@ void rto_trace_rays(const rt_flat_scene* s, int n, const float* rays7, float tmi
                     int use_bvh, rto_hit* out, rto_stats* st);
 void rto_object_hit(const rt_flat_scene* s, int object, int n, const float* rays7, float tmin, float tmax,
                     rto_hit* out);
+/* ... with the addressed draws of (seed, pixel, sample, bounce): a ConstantMedium object takes its free-flight draw */
+void rto_object_hit_addressed(const rt_flat_scene* s, int object, int n, const float* rays7, float tmin, float tmax,
+                              uint64_t seed, const uint32_t* pixel_sample_bounce3, rto_hit* out);
 void rto_trace_primary(const rt_flat_scene* s, int W, int H, float s_off, float t_off, int use_bvh,
                        int32_t* prim, float* t_out);
 void rto_texture_value(const rt_flat_scene* s, int texture, int n, const float* uvp5, float* rgb);

@@ -84,3 +84,30 @@ def test_two_rank_flow_rehearsal():
     assert js["scaling"] == "strong" and j1s["scaling"] == "strong" and js["config"]["spp_total"] == 16 and js["config"]["spp_per_gpu"] == 8
     assert abs(js["image_mean"] - j1s["image_mean"]) <= 1e-5 and abs(js["rays_per_sample"] - j1s["rays_per_sample"]) < 1e-9
     assert js["config"]["integrator"] == "wavefront"
+
+
+def test_collectives_execute_through_rccl_with_one_rank():
+    """No machine available to the build has two GPUs, so N > 1 over RCCL cannot run here.  What can: the same calls with
+    ONE rank.  RT_BENCH_FORCE_DIST=1 makes bench.py create the nccl (= RCCL) process group at N = 1 and run every collective
+    of the N > 1 flow -- reduce of the accumulation buffer onto rank 0 on the render stream, the two all-reduces of the
+    counters, the barriers, the teardown -- under the launcher the contract names.  The image must be the plain run's."""
+    W, H, spp = 64, 48, 8
+    common = ["--width", str(W), "--height", str(H), "--spp", str(spp), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
+    env = dict(os.environ, RT_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RT_BENCH_BACKEND", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29537", os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common,
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["n_gpus"] == 1 and "nccl" in j["config"]["parallelism"] and j["image_finite"]
+    # ... and without a launcher (bench.py supplies the rendezvous itself)
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=300, env=env)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    j2 = json.loads([ln for ln in r2.stdout.splitlines() if ln.startswith("{")][0])
+    plain = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=300)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    jp = json.loads([ln for ln in plain.stdout.splitlines() if ln.startswith("{")][0])
+    assert jp["config"]["parallelism"] == "single GPU"
+    assert j["image_mean"] == jp["image_mean"] == j2["image_mean"]
+    assert j["rays_per_sample"] == jp["rays_per_sample"]
