@@ -67,11 +67,13 @@
  * more waves fill issue slots, until the spills cost more.  Measured on the Cornell variant (current build): 5 waves
  * (96 VGPRs, no spill) 25.4 Grays/s, 6 (80 VGPRs, 9 spilled, 40 B of scratch per lane) 26.6, 7 (72 VGPRs, 28
  * spilled) 26.0; an early build read 4 -> 19.7, 5 -> 20.6, 6 -> 21.1, 8 -> 18.1.  Cornell smoke: 4 -> 22.6, 5 -> 24.2,
- * 6 -> 24.8.  The spills show up as scratch traffic in the counters (profiles/), far from any bandwidth limit. */
+ * 6 -> 24.8.  The spills show up as scratch traffic in the counters (profiles/), far from any bandwidth limit.
+ * Since the device code is built without SLP vectorisation (Makefile KFLAGS) the Cornell variant needs 72 VGPRs and
+ * spills nothing at 6 AND at 7 waves: 6 -> 28.0, 7 -> 28.6, 8 -> 28.1 Grays/s; Cornell smoke 25.5-25.7 at 6 either way. */
 constexpr int rt_render_waves(uint32_t F)
 {
 #ifndef RT_PLANAR_WAVES
-#define RT_PLANAR_WAVES 6
+#define RT_PLANAR_WAVES 7
 #endif
 #ifndef RT_MEDIA_WAVES
 #define RT_MEDIA_WAVES 6
