@@ -296,15 +296,15 @@ void rt_pack_bvh4(const rt_flat_scene* s, std::vector<DObj>& objs, std::vector<D
                         const float m = std::max(std::fabs(o.bmin[a]), std::fabs(o.bmax[a]));
                         float pad = 1e-5f * m + 1e-6f;
                         if (o.bmax[a] - o.bmin[a] < 2e-4f) pad += 1e-4f;
-                        d.box[k][a] = o.bmin[a] - pad; d.box[k][3 + a] = o.bmax[a] + pad;
+                        d.plane[a][0][k] = o.bmin[a] - pad; d.plane[a][1][k] = o.bmax[a] + pad;
                     }
                     d.ref[k] = refs[k];
                 } else if (k < nc) {
                     const rt_bvh_node& c = s->bvh_nodes[cands[k].node];
-                    for (int a = 0; a < 3; ++a) { d.box[k][a] = c.bmin[a]; d.box[k][3 + a] = c.bmax[a]; }
+                    for (int a = 0; a < 3; ++a) { d.plane[a][0][k] = c.bmin[a]; d.plane[a][1][k] = c.bmax[a]; }
                     d.ref[k] = refs[k];
                 } else {
-                    for (int a = 0; a < 3; ++a) { d.box[k][a] = 3.0e38f; d.box[k][3 + a] = -3.0e38f; }
+                    for (int a = 0; a < 3; ++a) { d.plane[a][0][k] = 3.0e38f; d.plane[a][1][k] = -3.0e38f; }
                     d.ref[k] = RT_REF_NONE;
                 }
                 d.pad[k] = 0;

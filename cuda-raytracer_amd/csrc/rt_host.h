@@ -75,7 +75,8 @@ enum {
  * slot is RT_REF_NONE with an inverted box).  Traversal there is bound by dependent fetches, and a 4-wide
  * step does the work of two or three binary ones per round trip. */
 struct alignas(16) DNode4 {
-    float   box[4][6];   /* per child: min xyz, max xyz */
+    float   plane[3][2][4];   /* [axis][0 = min, 1 = max][child]: AXIS-major, so that the four children's near planes along an
+                                 axis are ONE 16-byte load whose offset the ray's direction sign picks (rt_wavefront4.h) */
     int32_t ref[4];
     int32_t pad[4];
 };

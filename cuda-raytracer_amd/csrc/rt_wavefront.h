@@ -272,8 +272,9 @@ __global__ __launch_bounds__(RT_BLOCK, wf_intersect_waves(F)) void wf_intersect_
 
         if (interior) {
             const float4 n0 = nsrc[0], n1 = nsrc[1], n2 = nsrc[2], n3 = nsrc[3], n4 = nsrc[4], n5 = nsrc[5], n6 = nsrc[6];
-            const float b0[6] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y}, b1[6] = {n1.z, n1.w, n2.x, n2.y, n2.z, n2.w};
-            const float b2[6] = {n3.x, n3.y, n3.z, n3.w, n4.x, n4.y}, b3[6] = {n4.z, n4.w, n5.x, n5.y, n5.z, n5.w};
+            /* DNode4 is axis-major (n0 = the four children's min x, n1 = max x, n2 / n3 = y, n4 / n5 = z): a child's box is a column */
+            const float b0[6] = {n0.x, n2.x, n4.x, n1.x, n3.x, n5.x}, b1[6] = {n0.y, n2.y, n4.y, n1.y, n3.y, n5.y};
+            const float b2[6] = {n0.z, n2.z, n4.z, n1.z, n3.z, n5.z}, b3[6] = {n0.w, n2.w, n4.w, n1.w, n3.w, n5.w};
             int r0 = __float_as_int(n6.x), r1 = __float_as_int(n6.y), r2 = __float_as_int(n6.z), r3 = __float_as_int(n6.w);
             float t0, t1, t2, t3;
             /* a child that is missed (or an unused slot) sorts last with t = +inf */

@@ -52,11 +52,11 @@ static bool item_hit(const DObj& row, const Ray& r, float tmax, float& t)
     if ((row.head & 0xffu) != RT_OBJ_TRIANGLE) return false;      /* the light rect: ignored by the count */
     return tri_hit(row.f, r, .001f, tmax, t);
 }
-static bool slab(const float* lo, const float* hi, const Ray& r, const float* id, float tmax, float& tn)
+static bool slab(const DNode4& n, int child, const Ray& r, const float* id, float tmax, float& tn)      /* DNode4: planes axis-major */
 {
     float a = .001f, b = tmax;
     for (int k = 0; k < 3; ++k) {
-        float t0 = (lo[k] - r.o[k]) * id[k], t1 = (hi[k] - r.o[k]) * id[k];
+        float t0 = (n.plane[k][0][child] - r.o[k]) * id[k], t1 = (n.plane[k][1][child] - r.o[k]) * id[k];
         if (t0 > t1) std::swap(t0, t1);
         a = std::max(a, t0); b = std::min(b, t1);
     }
@@ -82,7 +82,7 @@ static float walk4(int root, const Ray& r, Count& c)
         c.nodes += 1;
         const DNode4& n = n4[(size_t)ref];
         std::pair<float, int> ch[4]; int m = 0;
-        for (int k = 0; k < 4; ++k) { float tn; if (n.ref[k] != RT_REF_NONE && slab(n.box[k], n.box[k] + 3, r, id, best, tn)) ch[m++] = {tn, n.ref[k]}; }
+        for (int k = 0; k < 4; ++k) { float tn; if (n.ref[k] != RT_REF_NONE && slab(n, k, r, id, best, tn)) ch[m++] = {tn, n.ref[k]}; }
         std::sort(ch, ch + m);
         for (int k = m - 1; k >= 0; --k) st.push_back(ch[k].second);
     }
