@@ -34,7 +34,8 @@ def test_every_bench_line_has_counters():
         assert e["rays"] > 0 and e["traffic_bytes_per_ray"] > 0 and e["lane_instructions_per_ray"] > 0
         # 4 x SQ_ACTIVE_INST_VALU over the SIMD cycles is not calibrated past 1 (instructions that hold a pipe for other than
         # four cycles): tools/make_profiles.py labels those "saturated" in valu_issue, and the figure stays a little above 1
-        assert 0.0 < e["valu_busy"] <= 1.15 and 0.0 < e["lane_efficiency"] <= 1.0
+        # (profiles/r03_valu_costs.jsonl: 2.4 to 9.4 cycles an instruction; 1.19 on the Cornell kernel at 7 waves per SIMD)
+        assert 0.0 < e["valu_busy"] <= 1.3 and 0.0 < e["lane_efficiency"] <= 1.0
         assert e["valu_issue"] == "saturated" or e["valu_busy"] < 0.98
         # the counter sums the entry was derived from are committed beside the table
         short = {"cornell": "cornell", "cornell_smoke": "smoke", "tri_mesh": "tri", "final": "final"}[wl]
