@@ -47,6 +47,7 @@ struct DScene {
     int32_t world;
     int32_t n_media;
     rt_camera cam;
+    const rt_camera*   __restrict__ cam_ptr; /* the same 96 bytes in device memory, for cam_fetch() */
 };
 
 __device__ __forceinline__ int      obj_type(uint32_t head)     { return (int)(head & 0xffu); }
@@ -990,6 +991,24 @@ __device__ __forceinline__ bool scatter(const DScene& S, const DRay& in, const H
 }
 
 /* ------------------------------------------------------------------ camera ---- */
+/* The camera block fetched by scalar loads AT THE POINT OF USE.  A render kernel starts a camera ray in most iterations of its
+ * loop, for a handful of lanes; read from the kernel arguments, the block's 24 words are loaded once and then held in SGPRs
+ * across the whole loop, where the scan program and the nested lane masks want them too: the allocator spilled them to
+ * VGPR lanes and fetched them back with two dozen v_readlane in every iteration (each a VALU instruction).  The empty asm
+ * makes the address new in every iteration, so the three s_load_dwordx8 stay where the ray is made; they hit the scalar
+ * cache and are waited for behind the Philox block that precedes the ray. */
+__device__ __forceinline__ rt_camera cam_fetch(const DScene& S)
+{
+    uintptr_t a = (uintptr_t)S.cam_ptr;
+    asm volatile("" : "+s"(a));
+    typedef const __attribute__((address_space(4))) rt_u32x8_t* const_cam_ptr;
+    static_assert(sizeof(rt_camera) == 3 * sizeof(rt_u32x8_t), "rt_camera is three 32-byte groups");
+    const rt_u32x8_t w[3] = {((const_cam_ptr)a)[0], ((const_cam_ptr)a)[1], ((const_cam_ptr)a)[2]};
+    rt_camera c;
+    __builtin_memcpy(&c, w, sizeof c);
+    return c;
+}
+
 template <uint32_t F>
 __device__ __forceinline__ DRay generate_ray(const rt_camera& c, float s, float t, float xi_time, const PathRng& g)   /* Camera.cuh:40-46 */
 {

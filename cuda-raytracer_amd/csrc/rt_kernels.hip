@@ -304,7 +304,7 @@ __global__ __launch_bounds__(RT_BLOCK, rt_render_waves(F)) void render_kernel(DS
             const uint32_t j = g.pixel / (uint32_t)W, i = g.pixel - j * (uint32_t)W;
             float u = float((int)i + rt_u32_to_uniform(cw.x)) / float(W);
             float v = float((int)j + rt_u32_to_uniform(cw.y)) / float(H);
-            ray = generate_ray<F>(S.cam, u, v, rt_u32_to_uniform(cw.z), g);
+            ray = generate_ray<F>(cam_fetch(S), u, v, rt_u32_to_uniform(cw.z), g);
             att = mk(1.f, 1.f, 1.f);
             emi = mk(0.f, 0.f, 0.f);
             depth = 0;
@@ -451,7 +451,7 @@ struct rt_ctx {
     float box_abs = 0.f;
     DScene ds;
     void* d_objs = nullptr;  void* d_ops = nullptr;   void* d_mats = nullptr; void* d_texs = nullptr;
-    void* d_image = nullptr; void* d_nodes = nullptr; void* d_leafs = nullptr; void* d_prog = nullptr; void* d_nodes4 = nullptr; void* d_nodes8 = nullptr; void* d_leafs8 = nullptr;
+    void* d_image = nullptr; void* d_nodes = nullptr; void* d_leafs = nullptr; void* d_prog = nullptr; void* d_nodes4 = nullptr; void* d_cam = nullptr; void* d_nodes8 = nullptr; void* d_leafs8 = nullptr;
     float* d_partial = nullptr; size_t partial_floats = 0;    /* per-group frames of the megakernel's sample groups */
     float* noalloc_scratch = nullptr;  /* this device's copy of rt_noalloc_scratch, looked up at rt_ctx_create */
     void* d_prog_wf = nullptr; void* d_wf_groups = nullptr;   /* the world list in the wavefront integrator's form */
@@ -465,7 +465,7 @@ struct rt_ctx {
 
 static void free_scene(rt_ctx* c)
 {
-    void** ptrs[] = {&c->d_objs, &c->d_ops, &c->d_mats, &c->d_texs, &c->d_image, &c->d_nodes, &c->d_leafs, &c->d_prog, &c->d_nodes4, &c->d_nodes8, &c->d_leafs8,
+    void** ptrs[] = {&c->d_objs, &c->d_ops, &c->d_mats, &c->d_texs, &c->d_image, &c->d_nodes, &c->d_leafs, &c->d_prog, &c->d_nodes4, &c->d_cam, &c->d_nodes8, &c->d_leafs8,
                      &c->d_prog_wf, &c->d_wf_groups};
     for (void** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
     c->have_scene = false;
@@ -568,6 +568,8 @@ extern "C" int rt_scene_upload(rt_ctx* c, const rt_flat_scene* s)
     std::vector<int> wf_groups;
     rt_pack_program(s, prog, &prog_wf, &wf_groups);
     if (stack_depth > RT_MAX_STACK) { rt_set_error("rt_scene_upload: BVH deeper than the traversal stack (64)"); return RT_ERR_UNSUPPORTED; }
+    /* the path kernel addresses a node row by a 32-bit byte offset from the table's base (rt_wavefront4.h) */
+    if (nodes4.size() >= ((size_t)1 << 24)) { rt_set_error("rt_scene_upload: more than 2^24 four-wide BVH nodes"); return RT_ERR_UNSUPPORTED; }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     free_scene(c);
@@ -597,6 +599,7 @@ extern "C" int rt_scene_upload(rt_ctx* c, const rt_flat_scene* s)
     if ((rc = upload(c, &c->d_leafs, leafs.data(), leafs.size()))) return rc;
     if ((rc = upload(c, &c->d_prog, prog.data(), prog.size()))) return rc;
     if ((rc = upload(c, &c->d_nodes4, nodes4.data(), nodes4.size()))) return rc;
+    if ((rc = upload(c, &c->d_cam, &s->camera, (size_t)1))) return rc;
     if ((rc = upload(c, &c->d_nodes8, nodes8.data(), nodes8.size()))) return rc;
     if ((rc = upload(c, &c->d_leafs8, leafs8.data(), leafs8.size()))) return rc;
     if ((rc = upload(c, &c->d_prog_wf, prog_wf.data(), prog_wf.size()))) return rc;
@@ -613,6 +616,7 @@ extern "C" int rt_scene_upload(rt_ctx* c, const rt_flat_scene* s)
     c->ds.leafs = (const DObj*)c->d_leafs;
     c->ds.prog = (const DProg*)c->d_prog;
     c->ds.nodes4 = (const DNode4*)c->d_nodes4;
+    c->ds.cam_ptr = (const rt_camera*)c->d_cam;
     c->ds.nodes8 = (const DNode8*)c->d_nodes8;
     c->ds.leafs8 = (const DLeaf*)c->d_leafs8;
     c->depth8 = depth8; c->n_nodes8 = nodes8.size(); c->box_abs = box_abs;

@@ -340,7 +340,7 @@ __device__ __forceinline__ void wf_start_sample(const DScene& S, const WfState& 
     rt_u32x4 cw = rng_block(g, RT_RNG_CAMERA, 0u, 0u);
     float u = float(i + rt_u32_to_uniform(cw.x)) / float(Wd);
     float v = float(j + rt_u32_to_uniform(cw.y)) / float(Hd);
-    DRay ray = generate_ray<F>(S.cam, u, v, rt_u32_to_uniform(cw.z), g);
+    DRay ray = generate_ray<F>(cam_fetch(S), u, v, rt_u32_to_uniform(cw.z), g);
     o4 = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.time);
     d4 = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(0u));
     a4 = make_float4(1.f, 1.f, 1.f, __uint_as_float(sample));
