@@ -88,6 +88,46 @@ constexpr int wf_intersect_waves(uint32_t F) { return (F & ~(RT_F_BVH | RT_F_TRI
  * scenes (tools/lib_sweep.py) */
 #endif
 
+/* The node step picks a box's near and far plane along an axis by the SIGN of the ray's direction instead of computing both
+ * distances and taking v_min / v_max of them: a min or max costs 1.7 multiplications on this chip (profiles/r03_valu_costs.jsonl)
+ * and a four-wide node step held 24 of them for this alone.  DNode4 is axis-major (rt_host.h): the four children's min x in
+ * one 16-byte group, their max x in the next, and so on, so "near" and "far" are two LOADS whose offsets differ in one bit
+ * that depends on the ray only.  Byte k of the result = offset of axis k's near group in the row: 32 k, + 16 when the ray
+ * runs towards negative k (sign bit of 1 / d, so -0 counts as negative like its reciprocal -inf); far = near ^ 16.
+ * The distances themselves are slab()'s: (plane - o) * (1 / d), near <= far by the monotonicity of rounding, NaNs (0 * inf)
+ * ignored by the v_max / v_min that remain, an unused slot's inverted box still a miss. */
+__device__ __forceinline__ uint32_t wf4_sign_offsets(V3 id)
+{
+    const uint32_t sx = __float_as_uint(id.x) >> 31, sy = __float_as_uint(id.y) >> 31, sz = __float_as_uint(id.z) >> 31;
+    return (sx << 4) | ((32u + (sy << 4)) << 8) | ((64u + (sz << 4)) << 16);
+}
+/* one child of the node: column k of the near / far plane groups */
+__device__ __forceinline__ bool wf4_child(float nx, float ny, float nz, float fx, float fy, float fz, V3 o, V3 id, float tMin, float tMax, float& tnear)
+{
+    const float tn = fmaxf(fmaxf((nx - o.x) * id.x, (ny - o.y) * id.y), fmaxf((nz - o.z) * id.z, tMin));
+    const float tf = fminf(fminf((fx - o.x) * id.x, (fy - o.y) * id.y), fminf((fz - o.z) * id.z, tMax));
+    tnear = tn;
+    return tn <= tf * 1.0000008f;
+}
+
+/* the node step's test of the four children of node `ref` (>= 0): loads, distances, and a child that is missed (or an unused
+ * slot) left with t = +inf and no reference.  Declares r0..r3 and t0..t3.  128-byte rows addressed by a 32-bit offset from
+ * the table's base (rt_scene_upload refuses tables beyond 2^24 nodes). */
+#define WF_NODE4_TEST(o_, id_, soff_, tMin_, tMax_)                                                                                   \
+            const char* nrow_ = reinterpret_cast<const char*>(S.nodes4);                                                              \
+            const uint32_t nbase_ = (uint32_t)ref << 7;                                                                               \
+            const uint32_t onx_ = nbase_ + ((soff_) & 0xffu), ony_ = nbase_ + (((soff_) >> 8) & 0xffu), onz_ = nbase_ + (((soff_) >> 16) & 0xffu); \
+            const float4 nx_ = *reinterpret_cast<const float4*>(nrow_ + onx_), fx_ = *reinterpret_cast<const float4*>(nrow_ + (onx_ ^ 16u)); \
+            const float4 ny_ = *reinterpret_cast<const float4*>(nrow_ + ony_), fy_ = *reinterpret_cast<const float4*>(nrow_ + (ony_ ^ 16u)); \
+            const float4 nz_ = *reinterpret_cast<const float4*>(nrow_ + onz_), fz_ = *reinterpret_cast<const float4*>(nrow_ + (onz_ ^ 16u)); \
+            const float4 n6_ = *reinterpret_cast<const float4*>(nrow_ + nbase_ + 96u);                                                \
+            int r0 = __float_as_int(n6_.x), r1 = __float_as_int(n6_.y), r2 = __float_as_int(n6_.z), r3 = __float_as_int(n6_.w);       \
+            float t0, t1, t2, t3;                                                                                                     \
+            if (!(wf4_child(nx_.x, ny_.x, nz_.x, fx_.x, fy_.x, fz_.x, o_, id_, tMin_, tMax_, t0) && r0 != RT_REF_NONE)) { t0 = FLT_MAX; r0 = RT_REF_NONE; } \
+            if (!(wf4_child(nx_.y, ny_.y, nz_.y, fx_.y, fy_.y, fz_.y, o_, id_, tMin_, tMax_, t1) && r1 != RT_REF_NONE)) { t1 = FLT_MAX; r1 = RT_REF_NONE; } \
+            if (!(wf4_child(nx_.z, ny_.z, nz_.z, fx_.z, fy_.z, fz_.z, o_, id_, tMin_, tMax_, t2) && r2 != RT_REF_NONE)) { t2 = FLT_MAX; r2 = RT_REF_NONE; } \
+            if (!(wf4_child(nx_.w, ny_.w, nz_.w, fx_.w, fy_.w, fz_.w, o_, id_, tMin_, tMax_, t3) && r3 != RT_REF_NONE)) { t3 = FLT_MAX; r3 = RT_REF_NONE; }
+
 /* ------------------------------------------------------------------ intersect -- */
 template <uint32_t F>
 __global__ __launch_bounds__(RT_BLOCK, wf_intersect_waves(F)) void wf_intersect_kernel(DScene S, WfState W, int qi, uint32_t k0, uint32_t k1,
@@ -105,6 +145,7 @@ __global__ __launch_bounds__(RT_BLOCK, wf_intersect_waves(F)) void wf_intersect_
     DRay rw = {mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f), 0.f}, rl_own = rw;
     DRay& rl = (F & RT_F_XFORM) ? rl_own : rw;      /* the ray in the group's frame: the world ray itself where no scene object is wrapped */
     V3 id = mk(0.f, 0.f, 0.f);
+    uint32_t soff = 0u;                         /* wf4_sign_offsets(id): where in a node row this ray's NEAR planes are */
     HitLite best = {FLT_MAX, -1, -1, 0};
     int gidx = 0, gi = -1, ref = RT_REF_NONE, pleaf = RT_REF_NONE, sp = 0, li = 0;
     int ovf[WF_OVF_STACK];                      /* stack entries beyond WF_LDS_STACK (scratch) */
@@ -121,6 +162,7 @@ __global__ __launch_bounds__(RT_BLOCK, wf_intersect_waves(F)) void wf_intersect_
             const DObj& o_ = S.objs[obj_];                                                                       \
             if (F & RT_F_XFORM) { rl = rw; apply_chain(S, o_, rl); }                                             \
             id = mk(1.f / rl.d.x, 1.f / rl.d.y, 1.f / rl.d.z);                                                   \
+            soff = wf4_sign_offsets(id);                                                                         \
             mode = WF_BVH; gi = obj_ == S.world ? -1 : obj_; ref = o_.pad[0]; pleaf = RT_REF_NONE; sp = 0; li = 0; \
         } else {                                                                                                 \
             W.hit[slot] = make_float4(best.t, __int_as_float(best.obj), __int_as_float(best.grp), __int_as_float(best.aux)); \
@@ -262,7 +304,6 @@ __global__ __launch_bounds__(RT_BLOCK, wf_intersect_waves(F)) void wf_intersect_
 #endif
         /* the loads of both steps of the trip go out together */
         const int lfirst = (~pleaf) >> 4, lcount = ((~pleaf) & 15) + 1;
-        const float4* nsrc = reinterpret_cast<const float4*>(S.nodes4 + (interior ? ref : 0));
         const float4* src = reinterpret_cast<const float4*>(S.leafs + (prim_step ? lfirst + li : 0));
         /* the leaf row first (zero-filled where no primitive step runs: leaving the registers undefined there made the
          * allocator spill, final scene 3.72 -> 2.65 Grays/s), then the node row inside the node step's own block, which
@@ -271,17 +312,8 @@ __global__ __launch_bounds__(RT_BLOCK, wf_intersect_waves(F)) void wf_intersect_
         if (prim_step) { q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3]; }
 
         if (interior) {
-            const float4 n0 = nsrc[0], n1 = nsrc[1], n2 = nsrc[2], n3 = nsrc[3], n4 = nsrc[4], n5 = nsrc[5], n6 = nsrc[6];
-            /* DNode4 is axis-major (n0 = the four children's min x, n1 = max x, n2 / n3 = y, n4 / n5 = z): a child's box is a column */
-            const float b0[6] = {n0.x, n2.x, n4.x, n1.x, n3.x, n5.x}, b1[6] = {n0.y, n2.y, n4.y, n1.y, n3.y, n5.y};
-            const float b2[6] = {n0.z, n2.z, n4.z, n1.z, n3.z, n5.z}, b3[6] = {n0.w, n2.w, n4.w, n1.w, n3.w, n5.w};
-            int r0 = __float_as_int(n6.x), r1 = __float_as_int(n6.y), r2 = __float_as_int(n6.z), r3 = __float_as_int(n6.w);
-            float t0, t1, t2, t3;
-            /* a child that is missed (or an unused slot) sorts last with t = +inf */
-            if (!(slab(b0, b0 + 3, rl.o, id, tMin, best.t, t0) && r0 != RT_REF_NONE)) { t0 = FLT_MAX; r0 = RT_REF_NONE; }
-            if (!(slab(b1, b1 + 3, rl.o, id, tMin, best.t, t1) && r1 != RT_REF_NONE)) { t1 = FLT_MAX; r1 = RT_REF_NONE; }
-            if (!(slab(b2, b2 + 3, rl.o, id, tMin, best.t, t2) && r2 != RT_REF_NONE)) { t2 = FLT_MAX; r2 = RT_REF_NONE; }
-            if (!(slab(b3, b3 + 3, rl.o, id, tMin, best.t, t3) && r3 != RT_REF_NONE)) { t3 = FLT_MAX; r3 = RT_REF_NONE; }
+            /* near / far planes picked by the ray's signs, as in the one-kernel form (WF_NODE4_TEST above) */
+            WF_NODE4_TEST(rl.o, id, soff, tMin, best.t)
             /* 5-exchange sorting network on (t, ref), nearest first */
 #define WF_CSWAP(ta, ra, tb, rb) { const bool sw_ = tb < ta; const float tt_ = sw_ ? tb : ta; const int rr_ = sw_ ? rb : ra; tb = sw_ ? ta : tb; rb = sw_ ? ra : rb; ta = tt_; ra = rr_; }
             WF_CSWAP(t0, r0, t1, r1) WF_CSWAP(t2, r2, t3, r3) WF_CSWAP(t0, r0, t2, r2) WF_CSWAP(t1, r1, t3, r3) WF_CSWAP(t1, r1, t2, r2)

@@ -47,28 +47,6 @@ constexpr bool wf4_inner_loop(uint32_t F) { return (F & ~(RT_F_BVH | RT_F_TRI | 
 #endif
 #define WF4_LDS_EXTRA_WORDS (7 * RT_BLOCK)      /* per lane: attenuation xyz, sum xyz; per wave: 64 ints for the ball draw */
 
-/* The node step picks a box's near and far plane along an axis by the SIGN of the ray's direction instead of computing both
- * distances and taking v_min / v_max of them: a min or max costs 1.7 multiplications on this chip (profiles/r03_valu_costs.jsonl)
- * and a four-wide node step held 24 of them for this alone.  DNode4 is axis-major (rt_host.h): the four children's min x in
- * one 16-byte group, their max x in the next, and so on, so "near" and "far" are two LOADS whose offsets differ in one bit
- * that depends on the ray only.  Byte k of the result = offset of axis k's near group in the row: 32 k, + 16 when the ray
- * runs towards negative k (sign bit of 1 / d, so -0 counts as negative like its reciprocal -inf); far = near ^ 16.
- * The distances themselves are slab()'s: (plane - o) * (1 / d), near <= far by the monotonicity of rounding, NaNs (0 * inf)
- * ignored by the v_max / v_min that remain, an unused slot's inverted box still a miss. */
-__device__ __forceinline__ uint32_t wf4_sign_offsets(V3 id)
-{
-    const uint32_t sx = __float_as_uint(id.x) >> 31, sy = __float_as_uint(id.y) >> 31, sz = __float_as_uint(id.z) >> 31;
-    return (sx << 4) | ((32u + (sy << 4)) << 8) | ((64u + (sz << 4)) << 16);
-}
-/* one child of the node: column k of the near / far plane groups */
-__device__ __forceinline__ bool wf4_child(float nx, float ny, float nz, float fx, float fy, float fz, V3 o, V3 id, float tMin, float tMax, float& tnear)
-{
-    const float tn = fmaxf(fmaxf((nx - o.x) * id.x, (ny - o.y) * id.y), fmaxf((nz - o.z) * id.z, tMin));
-    const float tf = fminf(fminf((fx - o.x) * id.x, (fy - o.y) * id.y), fminf((fz - o.z) * id.z, tMax));
-    tnear = tn;
-    return tn <= tf * 1.0000008f;
-}
-
 /* MG: the world list holds more than one BVH group (the final scene: the box floor and the sphere cluster).  With a single
  * group (the triangle mesh) a ray enters it in the refill and is finished when it leaves it: the trip loop then carries
  * no entry block at all. */
@@ -346,8 +324,6 @@ __global__ __launch_bounds__(RT_BLOCK, wf4_waves(F)) void wf_path_kernel(DScene 
         }
 #endif
         const int lfirst = (~pleaf) >> 4, lcount = ((~pleaf) & 15) + 1;
-        const char* nrow = reinterpret_cast<const char*>(S.nodes4);
-        const uint32_t nbase = interior ? (uint32_t)ref << 7 : 0u;      /* 128-byte rows; the tables stay far below 4 GB */
         const float4* src = reinterpret_cast<const float4*>(S.leafs + (prim_step ? lfirst + li : 0));
         /* the leaf row, loaded only by the lanes that take a primitive step.  The other lanes' copies must still be DEFINED
          * (left undefined, the allocator spilled: final scene 3.72 -> 2.65 Grays/s in wf_intersect_kernel), which cost 16 zero
@@ -363,17 +339,7 @@ __global__ __launch_bounds__(RT_BLOCK, wf4_waves(F)) void wf_path_kernel(DScene 
         if (prim_step) { q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3]; }
 
         if (interior) {
-            const uint32_t onx = nbase + (soff & 0xffu), ony = nbase + ((soff >> 8) & 0xffu), onz = nbase + ((soff >> 16) & 0xffu);
-#define WF4_ROW(off) (*reinterpret_cast<const float4*>(nrow + (off)))
-            const float4 nx = WF4_ROW(onx), fx = WF4_ROW(onx ^ 16u), ny = WF4_ROW(ony), fy = WF4_ROW(ony ^ 16u);
-            const float4 nz = WF4_ROW(onz), fz = WF4_ROW(onz ^ 16u), n6 = WF4_ROW(nbase + 96u);
-#undef WF4_ROW
-            int r0 = __float_as_int(n6.x), r1 = __float_as_int(n6.y), r2 = __float_as_int(n6.z), r3 = __float_as_int(n6.w);
-            float t0, t1, t2, t3;
-            if (!(wf4_child(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, rl.o, id, tMin, best.t, t0) && r0 != RT_REF_NONE)) { t0 = FLT_MAX; r0 = RT_REF_NONE; }
-            if (!(wf4_child(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, rl.o, id, tMin, best.t, t1) && r1 != RT_REF_NONE)) { t1 = FLT_MAX; r1 = RT_REF_NONE; }
-            if (!(wf4_child(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, rl.o, id, tMin, best.t, t2) && r2 != RT_REF_NONE)) { t2 = FLT_MAX; r2 = RT_REF_NONE; }
-            if (!(wf4_child(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, rl.o, id, tMin, best.t, t3) && r3 != RT_REF_NONE)) { t3 = FLT_MAX; r3 = RT_REF_NONE; }
+            WF_NODE4_TEST(rl.o, id, soff, tMin, best.t)
 #define WF_CSWAP(ta, ra, tb, rb) { const bool sw_ = tb < ta; const float tt_ = sw_ ? tb : ta; const int rr_ = sw_ ? rb : ra; tb = sw_ ? ta : tb; rb = sw_ ? ra : rb; ta = tt_; ra = rr_; }
             WF_CSWAP(t0, r0, t1, r1) WF_CSWAP(t2, r2, t3, r3) WF_CSWAP(t0, r0, t2, r2) WF_CSWAP(t1, r1, t3, r3) WF_CSWAP(t1, r1, t2, r2)
 #undef WF_CSWAP
