@@ -243,6 +243,39 @@ def test_render_equals_oracle_sample_for_sample(binding, oracle, gpu_ctx, name, 
     assert exp.sum() > 0
 
 
+@pytest.mark.parametrize("integrator", INTEGRATORS)
+@pytest.mark.parametrize("name,param,axis,at", [("tri_mesh", 4000, 0, None), ("tri_mesh", 4000, 1, 20.37), ("bvh_boxes", 0, 0, None),
+                                                ("cornell_cluster", 0, 0, None)])
+def test_axis_parallel_camera_rays_through_the_trees(binding, oracle, gpu_ctx, name, param, axis, at, integrator):
+    """Every camera ray with a direction component of exactly +0 (1/d = +inf, planes at 0 * inf = NaN): what a render never
+    produces by chance and the special-ray fixture only sends through rt_trace_rays_wavefront.  The camera block of the
+    flat scene is edited in place -- no horizontal or vertical extent along the axis, lower-left corner level with the
+    origin along it -- so that lower_left + s h + t v - origin is +0 there for every (s, t), and the whole render
+    (both integrators; the one-kernel wavefront form picks a node's near and far planes by the SIGN of 1/d) must still
+    follow the oracle's paths sample for sample."""
+    W, H, spp = 24, 40, 4
+    sc = binding.Scene(name, W, H, param)
+    cam = sc.flat.contents.camera
+    cam.horizontal[axis] = 0.0
+    cam.vertical[axis] = 0.0
+    cam.origin[axis] = cam.origin[axis] + 0.37 if at is None else at      # off the scene's own grid lines; `at`: level with the terrain
+    cam.lower_left[axis] = cam.origin[axis]
+    assert cam.lens_radius == 0.0
+    rays = oracle.camera_rays(sc.flat, np.random.default_rng(3).random((64, 2)).astype(np.float32), 419,
+                              np.stack([np.arange(64), np.arange(64)], axis=1).astype(np.uint32))
+    assert (rays[:, 3 + axis] == 0).all() and not np.signbit(rays[:, 3 + axis]).any()
+    gpu_ctx.upload(sc)
+    gpu_ctx.reset_counters()
+    got = render_gpu(gpu_ctx, binding, sc, W, H, 0, spp, 419, integrator=integrator).cpu().numpy().reshape(H, W, 3)
+    c = gpu_ctx.counters()
+    exp, st = oracle.render(sc.flat, W, H, 0, spp, 419, 100, sc.background, threads=8)
+    assert np.isfinite(got).all()
+    bad = np.any(np.abs(got - exp) > 1e-4 * (1 + np.abs(exp)), axis=2)
+    assert bad.mean() <= 0.01, "%d of %d pixels differ" % (bad.sum(), bad.size)
+    assert abs(int(c.rays) - int(st.rays)) <= 0.01 * st.rays
+    assert st.rays > W * H * spp        # the rays do meet the scene and bounce
+
+
 @pytest.mark.parametrize("variant", ["list", "all"])
 @pytest.mark.parametrize("integrator", INTEGRATORS)
 @pytest.mark.parametrize("name", ["cornell", "cornell_smoke"])
