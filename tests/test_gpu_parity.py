@@ -245,7 +245,7 @@ def test_render_equals_oracle_sample_for_sample(binding, oracle, gpu_ctx, name, 
 
 @pytest.mark.parametrize("integrator", INTEGRATORS)
 @pytest.mark.parametrize("name,param,axis,at", [("tri_mesh", 4000, 0, None), ("tri_mesh", 4000, 1, 20.37), ("bvh_boxes", 0, 0, None),
-                                                ("cornell_cluster", 0, 0, None)])
+                                                ("cornell_cluster", 0, 0, None), ("random_spheres", 0, 0, "minus zero")])
 def test_axis_parallel_camera_rays_through_the_trees(binding, oracle, gpu_ctx, name, param, axis, at, integrator):
     """Every camera ray with a direction component of exactly +0 (1/d = +inf, planes at 0 * inf = NaN): what a render never
     produces by chance and the special-ray fixture only sends through rt_trace_rays_wavefront.  The camera block of the
@@ -258,12 +258,23 @@ def test_axis_parallel_camera_rays_through_the_trees(binding, oracle, gpu_ctx, n
     cam = sc.flat.contents.camera
     cam.horizontal[axis] = 0.0
     cam.vertical[axis] = 0.0
-    cam.origin[axis] = cam.origin[axis] + 0.37 if at is None else at      # off the scene's own grid lines; `at`: level with the terrain
-    cam.lower_left[axis] = cam.origin[axis]
+    minus = at == "minus zero"
+    if minus:
+        # (-0 + s * -0 + t * -0) - (+0) - (+0) = -0: 1/d = -inf, the ray "runs towards negative x" without moving along it.
+        # Only an origin at 0 gives it (x - x is +0), so the camera is moved into the plane x = 0, which cuts the random
+        # spheres generically.  (On the terrain x = 0 is a grid line: rays along shared triangle edges, where a BVH and the
+        # flat list may legitimately disagree -- conftest.special_order_free.)
+        cam.origin[axis] = 0.0
+        cam.horizontal[axis] = -0.0
+        cam.vertical[axis] = -0.0
+        cam.lower_left[axis] = -0.0
+    else:
+        cam.origin[axis] = cam.origin[axis] + 0.37 if at is None else at      # off the scene's own grid lines; `at`: level with the terrain
+        cam.lower_left[axis] = cam.origin[axis]
     assert cam.lens_radius == 0.0
     rays = oracle.camera_rays(sc.flat, np.random.default_rng(3).random((64, 2)).astype(np.float32), 419,
                               np.stack([np.arange(64), np.arange(64)], axis=1).astype(np.uint32))
-    assert (rays[:, 3 + axis] == 0).all() and not np.signbit(rays[:, 3 + axis]).any()
+    assert (rays[:, 3 + axis] == 0).all() and bool(np.signbit(rays[:, 3 + axis]).any()) == minus      # (a few come out as +0: -0 + s * -0 with s = 0)
     gpu_ctx.upload(sc)
     gpu_ctx.reset_counters()
     got = render_gpu(gpu_ctx, binding, sc, W, H, 0, spp, 419, integrator=integrator).cpu().numpy().reshape(H, W, 3)
