@@ -11,6 +11,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
 @pytest.mark.parametrize("workload,extra", [("cornell", []), ("tri_mesh", ["--param", "3000"])])
 def test_bench_line_and_image(binding, gpu_ctx, workload, extra):
     import torch
@@ -58,7 +65,7 @@ def test_two_rank_flow_rehearsal():
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["image_finite"] and "REHEARSAL" in j["config"]["parallelism"]
     # ... and under the launcher (the contract's form): same line
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common,
+                        "--master-port", free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common,
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     jl = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
@@ -96,7 +103,7 @@ def test_collectives_execute_through_rccl_with_one_rank():
     env = dict(os.environ, RT_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("RT_BENCH_BACKEND", None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                        "--master-port", "29537", os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common,
+                        "--master-port", free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common,
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
